@@ -1,0 +1,473 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference).  The reference's
+model files are imported *by path* (they import nothing but torch; the package
+itself is not pip-installed) and driven with the call sequence of
+  - validation/validate_rnn.py:59-60,82-83   (forward + softmax)
+  - utils/training_utils.py:484-525          (train_step)
+to produce input/output vectors.  Random draws are pinned by capture:
+  - Bayesian eps: Tensor.normal_ is wrapped to record every draw
+    (bayesian_rnn.py:492-523, 608);
+  - Variational / vanilla-train masks: replayed after re-seeding with the same
+    `empty(shape).bernoulli_(1-p).div_(1-p)` sequence ATen uses, in the draw
+    order pinned in SURVEY.md 8a, then VERIFIED here by pushing them through the
+    C oracle and comparing with the reference logits.
+
+Only data (inputs, weights, draws, outputs) is written -- no reference source.
+"""
+import importlib.util
+import io
+import contextlib
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pack_padded_sequence
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+REF = "/root/reference/python/supernnova/training"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location("ref_" + name, f"{REF}/{name}.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+vanilla_rnn = _load("vanilla_rnn")
+variational_rnn = _load("variational_rnn")
+bayesian_rnn = _load("bayesian_rnn")
+
+
+def settings(**kw):
+    d = dict(layer_type="lstm", nb_classes=2, hidden_dim=32, num_layers=2, dropout=0.05,
+             bidirectional=True, use_cuda=False, rnn_output_option="mean",
+             pi=0.75, log_sigma1=-1.0, log_sigma2=-7.0, rho_scale_lower=4.0, rho_scale_upper=3.0,
+             log_sigma1_output=-1.0, log_sigma2_output=-7.0,
+             rho_scale_lower_output=4.0, rho_scale_upper_output=3.0)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def build(cls, D, st):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return cls(D, st)
+
+
+def make_batch(seed, T, B, D, lengths=None):
+    g = np.random.default_rng(seed)
+    if lengths is None:
+        lengths = np.sort(g.integers(3, T + 1, size=B))[::-1].copy()
+        lengths[0] = T
+    lengths = np.asarray(lengths, dtype=np.int64)
+    x = g.standard_normal((T, B, D)).astype(np.float32)
+    for b in range(B):
+        x[lengths[b]:, b] = 0
+    return x, lengths
+
+
+# ---------------------------------------------------------------- flat layouts
+def flat_vanilla(sd, L, dirs):
+    out = []
+    for l in range(L):
+        for d in range(dirs):
+            s = "_reverse" if d else ""
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                out.append(sd[f"rnn_layer.{n}_l{l}{s}"].reshape(-1))
+    out += [sd["output_layer.weight"].reshape(-1), sd["output_layer.bias"].reshape(-1)]
+    return np.concatenate(out).astype(np.float32)
+
+
+def flat_variational(sd, L, dirs):
+    out = []
+    for l in range(L):
+        for d in range(dirs):
+            s = "_reverse" if d else ""
+            hh = "weight_hh_l0_raw" if d == 0 else "weight_hh_l0_reverse"
+            for n in (f"weight_ih_l0{s}", hh, f"bias_ih_l0{s}", f"bias_hh_l0{s}"):
+                out.append(sd[f"rnn_layer{l}.module.{n}"].reshape(-1))
+    out += [sd["output_layer.weight"].reshape(-1), sd["output_layer.bias"].reshape(-1)]
+    return np.concatenate(out).astype(np.float32)
+
+
+def flat_bayes(sd, L, dirs, which):
+    out = []
+    for l in range(L):
+        for d in range(dirs):
+            s = "_reverse" if d else ""
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                out.append(sd[f"rnn_layer.{n}_{which}_l{l}{s}"].reshape(-1))
+    out.append(sd[f"output_layer.{which}"].reshape(-1))
+    return np.concatenate(out).astype(np.float32)
+
+
+def sd_np(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = np.asarray(vv)
+        else:
+            flat[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+def ocfg(st, D):
+    return oracle.make_cfg(D, st.hidden_dim, st.num_layers, st.bidirectional, st.nb_classes,
+                           st.rnn_output_option)
+
+
+def check(tag, a, b, tol=2e-6):
+    err = float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+    print(f"  [{tag}] oracle vs reference max abs diff = {err:.3e}")
+    assert err < tol, (tag, err)
+
+
+def softmax(t):
+    return torch.nn.functional.softmax(t, dim=-1).data.cpu().numpy()
+
+
+def bern(shape, p):
+    return torch.empty(shape).bernoulli_(1 - p).div_(1 - p).numpy().copy()
+
+
+# ---------------------------------------------------------------- G1 vanilla
+def g1_vanilla():
+    st = settings()
+    D = 24
+    m = build(vanilla_rnn.VanillaRNN, D, st)
+    sd = torch.load("/root/reference/tests/onthefly_model/"
+                    "vanilla_S_0_CLF_2_R_none_photometry_DF_1.0_N_global_lstm_32x2_0.05_128_True_mean.pt",
+                    weights_only=True)
+    m.load_state_dict(sd)
+    m.eval()
+    sdn = sd_np(m)
+    w = flat_vanilla(sdn, 2, 2)
+    cfg = ocfg(st, D)
+    lens = [30, 28, 25, 25, 20, 18, 17, 15, 12, 10, 9, 8, 6, 5, 4, 3]
+    x, lengths = make_batch(1, 30, 16, D, lens)
+    with torch.no_grad():
+        lo = m(pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths)))
+        lo_dense = m(torch.from_numpy(x))           # un-packed path: runs over padding, /T
+        x1, l1 = make_batch(2, 18, 1, D, [18])
+        lo_b1 = m(pack_padded_sequence(torch.from_numpy(x1), torch.from_numpy(l1)))
+    o = oracle.forward(cfg, x, lengths, w)
+    check("vanilla packed", o["logits"], lo.numpy())
+    od = oracle.forward(cfg, x, np.full(16, 30), w)
+    check("vanilla dense", od["logits"], lo_dense.numpy())
+    o1 = oracle.forward(cfg, x1, l1, w)
+    check("vanilla B=1", o1["logits"], lo_b1.numpy())
+    save("g1_vanilla_mean", sd=sdn, x=x, lengths=lengths, logits=lo.numpy(), probs=softmax(lo),
+         logits_dense=lo_dense.numpy(), x_b1=x1, lengths_b1=l1, logits_b1=lo_b1.numpy(),
+         probs_b1=softmax(lo_b1))
+
+    # standard pooling, random weights, C=3, D=26 (redshift features)
+    torch.manual_seed(11)
+    st2 = settings(rnn_output_option="standard", nb_classes=3)
+    D2 = 26
+    m2 = build(vanilla_rnn.VanillaRNN, D2, st2)
+    m2.eval()
+    x2, l2 = make_batch(3, 21, 37, D2)
+    with torch.no_grad():
+        lo2 = m2(pack_padded_sequence(torch.from_numpy(x2), torch.from_numpy(l2)))
+    sd2 = sd_np(m2)
+    o2 = oracle.forward(ocfg(st2, D2), x2, l2, flat_vanilla(sd2, 2, 2))
+    check("vanilla standard", o2["logits"], lo2.numpy())
+    save("g1_vanilla_standard", sd=sd2, x=x2, lengths=l2, logits=lo2.numpy(), probs=softmax(lo2))
+
+
+# ---------------------------------------------------------------- G2 variational
+def var_masks(st, D, B, F):
+    """Draw order pinned in SURVEY 8a: (1) input (1,B,D); per layer: W_hh row mask (4H,1)
+    [+ locked (1,B,2H) between layers]; (4) output (B,F)."""
+    p, H, L = st.dropout, st.hidden_dim, st.num_layers
+    dirs = 2 if st.bidirectional else 1
+    mask_in = bern((1, B, D), p)[0]
+    whh, mid = [], []
+    for l in range(L):
+        whh.append(bern((4 * H, 1), p)[:, 0])
+        if l != L - 1:
+            mid.append(bern((1, B, dirs * H), p)[0])
+    mask_out = bern((B, F), p)
+    return mask_in, np.stack(whh), (np.stack(mid) if mid else None), mask_out
+
+
+def g2_variational():
+    for tag, kw, D, T, B, seed in (("mean", {}, 24, 30, 48, 21),
+                                   ("standard", dict(rnn_output_option="standard", nb_classes=4), 26, 17, 33, 22)):
+        st = settings(**kw)
+        torch.manual_seed(seed)
+        m = build(variational_rnn.VariationalRNN, D, st)
+        m.eval()
+        sdn = sd_np(m)
+        cfg = ocfg(st, D)
+        F = oracle.feat(cfg)
+        w = flat_variational(sdn, 2, 2)
+        x, lengths = make_batch(seed, T, B, D)
+        packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+        S = 3
+        all_masks, all_logits = [], []
+        for s in range(S):
+            torch.manual_seed(1000 + s)
+            with torch.no_grad():
+                lo = m(packed)
+            torch.manual_seed(1000 + s)
+            mk = var_masks(st, D, B, F)
+            o = oracle.forward(cfg, x, lengths, w, *mk)
+            check(f"variational {tag} s={s}", o["logits"], lo.numpy())
+            all_masks.append(mk)
+            all_logits.append(lo.numpy())
+        with torch.no_grad():
+            lo_mfe = m(packed, mean_field_inference=True)
+            torch.manual_seed(77)
+            lo_dense = m(torch.from_numpy(x))
+        torch.manual_seed(77)
+        mk_d = var_masks(st, D, B, F)
+        check(f"variational {tag} mfe", oracle.forward(cfg, x, lengths, w)["logits"], lo_mfe.numpy())
+        check(f"variational {tag} dense",
+              oracle.forward(cfg, x, np.full(B, T), w, *mk_d)["logits"], lo_dense.numpy())
+        logits = np.stack(all_logits)
+        save(f"g2_variational_{tag}", sd=sdn, x=x, lengths=lengths,
+             mask_in=np.stack([a[0] for a in all_masks]), mask_whh=np.stack([a[1] for a in all_masks]),
+             mask_mid=np.stack([a[2] for a in all_masks]), mask_out=np.stack([a[3] for a in all_masks]),
+             logits=logits, probs=softmax(torch.from_numpy(logits)),
+             logits_mfe=lo_mfe.numpy(), logits_dense=lo_dense.numpy(),
+             dense_mask_in=mk_d[0], dense_mask_whh=mk_d[1], dense_mask_mid=mk_d[2], dense_mask_out=mk_d[3],
+             dropout=np.float32(st.dropout))
+
+
+# ---------------------------------------------------------------- G3 bayesian
+class EpsCapture:
+    """Record every Tensor.normal_ draw (the reference's only RNG use in BayesianRNN.forward)."""
+
+    def __enter__(self):
+        self.draws = []
+        self._orig = torch.Tensor.normal_
+        cap = self
+
+        def normal_(t, *a, **k):
+            r = cap._orig(t, *a, **k)
+            cap.draws.append(r.detach().numpy().reshape(-1).copy())
+            return r
+
+        torch.Tensor.normal_ = normal_
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.normal_ = self._orig
+
+    def flat(self):
+        return np.concatenate(self.draws).astype(np.float32)
+
+
+def bayes_oracle(st, cfg, sdn, x, lengths, eps):
+    mu = flat_bayes(sdn, st.num_layers, 2 if st.bidirectional else 1, "mu")
+    rho = flat_bayes(sdn, st.num_layers, 2 if st.bidirectional else 1, "rho")
+    w, sigma = oracle.bbb_sample(mu, rho, eps)
+    kl = oracle.kl(cfg, w, mu, sigma, st.pi, st.log_sigma1, st.log_sigma2,
+                   st.log_sigma1_output, st.log_sigma2_output)
+    wfull = np.concatenate([w, sdn["output_layer.bias"].reshape(-1)])
+    return oracle.forward(cfg, x, lengths, wfull), kl, w
+
+
+def g3_bayesian():
+    cases = (("mean", {}, 24, 30, 40, 31),
+             ("standard", dict(rnn_output_option="standard", nb_classes=3), 26, 19, 35, 32),
+             ("h64", dict(hidden_dim=64, nb_classes=5), 24, 12, 9, 33),
+             ("h128_d78", dict(hidden_dim=128, nb_classes=14), 78, 60, 5, 34))
+    for tag, kw, D, T, B, seed in cases:
+        st = settings(**kw)
+        torch.manual_seed(seed)
+        S = {"h64": 2, "h128_d78": 1}.get(tag, 3)   # keep the big-H fixtures small
+        m = build(bayesian_rnn.BayesianRNN, D, st)
+        m.eval()
+        # move rho/mu off their init a little so the test is not init-specific
+        with torch.no_grad():
+            m.output_layer.bias.uniform_(-0.1, 0.1)
+            for n, p in m.named_parameters():
+                if "mu" in n:
+                    p.mul_(4.0)
+        sdn = sd_np(m)
+        cfg = ocfg(st, D)
+        x, lengths = make_batch(seed, T, B, D)
+        packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+        eps_all, logits_all, kl_all = [], [], []
+        for s in range(S):
+            torch.manual_seed(2000 + s)
+            with EpsCapture() as cap, torch.no_grad():
+                lo = m(packed)
+            eps = cap.flat()
+            o, kl, _ = bayes_oracle(st, cfg, sdn, x, lengths, eps)
+            check(f"bayesian {tag} s={s}", o["logits"], lo.numpy(), tol=5e-6)
+            klr = float(m.kl)
+            print(f"  [bayesian {tag} s={s}] kl oracle {kl:.6f} ref {klr:.6f} rel {abs(kl - klr) / abs(klr):.2e}")
+            assert abs(kl - klr) / abs(klr) < 2e-6
+            eps_all.append(eps)
+            logits_all.append(lo.numpy())
+            kl_all.append(klr)
+        with torch.no_grad():
+            lo_mfe = m(packed, mean_field_inference=True)
+            kl_mfe = float(m.kl)
+            torch.manual_seed(2100)
+            with EpsCapture() as cap:
+                lo_dense = m(torch.from_numpy(x))
+            eps_dense = cap.flat()
+        o, kl, _ = bayes_oracle(st, cfg, sdn, x, lengths, None)
+        check(f"bayesian {tag} mfe", o["logits"], lo_mfe.numpy(), tol=5e-6)
+        assert abs(kl - kl_mfe) / abs(kl_mfe) < 2e-6, (kl, kl_mfe)
+        o, _, _ = bayes_oracle(st, cfg, sdn, x, np.full(B, T), eps_dense)
+        check(f"bayesian {tag} dense", o["logits"], lo_dense.numpy(), tol=5e-6)
+        logits = np.stack(logits_all)
+        save(f"g3_bayesian_{tag}", sd=sdn, x=x, lengths=lengths, eps=np.stack(eps_all),
+             logits=logits, probs=softmax(torch.from_numpy(logits)), kl=np.array(kl_all, np.float64),
+             logits_mfe=lo_mfe.numpy(), kl_mfe=np.float64(kl_mfe),
+             logits_dense=lo_dense.numpy(), eps_dense=eps_dense)
+
+
+# ---------------------------------------------------------------- G4 train step
+def ref_train_step(rnn, packed, target, optimizer, batch_size, num_batches, is_bayes):
+    """Call sequence of utils/training_utils.py:508-525."""
+    criterion = torch.nn.CrossEntropyLoss()
+    rnn.train()
+    optimizer.zero_grad()
+    output = rnn(packed)
+    loss = criterion(output.squeeze(), target)
+    if is_bayes:
+        loss = loss + rnn.kl / (num_batches * batch_size)
+    loss.backward()
+    grads = {n: p.grad.detach().numpy().copy() for n, p in rnn.named_parameters()}
+    optimizer.step()
+    return float(loss), grads, output.detach().numpy().copy()
+
+
+def g4_train():
+    D, T, B = 24, 24, 32
+    num_batches = 7
+    for model in ("bayesian", "variational", "vanilla"):
+        st = settings()
+        torch.manual_seed(41)
+        cls = dict(bayesian=bayesian_rnn.BayesianRNN, variational=variational_rnn.VariationalRNN,
+                   vanilla=vanilla_rnn.VanillaRNN)[model]
+        m = build(cls, D, st)
+        sd0 = sd_np(m)
+        x, lengths = make_batch(42, T, B, D)
+        target = np.random.default_rng(43).integers(0, 2, size=B).astype(np.int64)
+        packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+        wd = 1e-7 if model == "variational" else 0.0   # experiment_settings.py:40-43
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=wd)
+        extra = {}
+        steps = 2
+        losses, grads_all, sds, outs = [], [], [], []
+        for it in range(steps):
+            torch.manual_seed(4000 + it)
+            if model == "bayesian":
+                with EpsCapture() as cap:
+                    loss, grads, out = ref_train_step(m, packed, torch.from_numpy(target), opt, B, num_batches, True)
+                extra.setdefault("eps", []).append(cap.flat())
+            else:
+                loss, grads, out = ref_train_step(m, packed, torch.from_numpy(target), opt, B, num_batches, False)
+                torch.manual_seed(4000 + it)
+                if model == "variational":
+                    mk = var_masks(st, D, B, 64)
+                    for k, v in zip(("mask_in", "mask_whh", "mask_mid", "mask_out"), mk):
+                        extra.setdefault(k, []).append(v)
+                else:
+                    # torch.nn.LSTM(dropout=p) in train mode: element mask on the packed
+                    # layer-0 output (sum(len), 2H), then nn.Dropout on the pooled (B, 2H)
+                    n_tok = int(lengths.sum())
+                    mid_packed = bern((n_tok, 64), st.dropout)
+                    mask_out = bern((B, 64), st.dropout)
+                    mid = np.zeros((1, T, B, 64), np.float32)
+                    bs = packed.batch_sizes.numpy()
+                    off = 0
+                    for t in range(T):
+                        mid[0, t, :bs[t]] = mid_packed[off:off + bs[t]]
+                        off += bs[t]
+                    extra.setdefault("mask_mid", []).append(mid)
+                    extra.setdefault("mask_out", []).append(mask_out)
+            losses.append(loss)
+            grads_all.append(grads)
+            outs.append(out)
+            sds.append(sd_np(m))
+        # verify the captured draws reproduce the train-mode logits of step 0 through the oracle
+        cfg = ocfg(st, D)
+        if model == "bayesian":
+            o, _, _ = bayes_oracle(st, cfg, sd0, x, lengths, extra["eps"][0])
+        elif model == "variational":
+            o = oracle.forward(cfg, x, lengths, flat_variational(sd0, 2, 2), extra["mask_in"][0],
+                               extra["mask_whh"][0], extra["mask_mid"][0], extra["mask_out"][0])
+        else:
+            o = oracle.forward(cfg, x, lengths, flat_vanilla(sd0, 2, 2), None, None,
+                               extra["mask_mid"][0], extra["mask_out"][0])
+        check(f"train {model} step0 logits", o["logits"], outs[0], tol=5e-6)
+        arrs = dict(sd0=sd0, x=x, lengths=lengths, target=target,
+                    num_batches=np.int64(num_batches), batch_size=np.int64(B),
+                    lr=np.float64(1e-3), weight_decay=np.float64(wd), dropout=np.float32(st.dropout),
+                    loss=np.array(losses, np.float64), logits=np.stack(outs))
+        for it in range(steps):
+            arrs[f"grads{it}"] = grads_all[it]
+            arrs[f"sd{it + 1}"] = sds[it]
+        for k, v in extra.items():
+            arrs[k] = np.stack(v)
+        save(f"g4_train_{model}", **arrs)
+
+
+# ---------------------------------------------------------------- G5 MC statistics
+def g5_mc_stats():
+    D, T, B, S = 24, 40, 256, 50
+    for model in ("bayesian", "variational"):
+        st = settings()
+        torch.manual_seed(51)
+        cls = dict(bayesian=bayesian_rnn.BayesianRNN, variational=variational_rnn.VariationalRNN)[model]
+        m = build(cls, D, st)
+        if model == "variational":
+            st.dropout = 0.05
+        else:
+            with torch.no_grad():      # widen the posterior so std is well resolved
+                for n, p in m.named_parameters():
+                    if "mu" in n:
+                        p.mul_(6.0)
+        m.eval()
+        x, lengths = make_batch(52, T, B, D)
+        packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+        torch.manual_seed(5000)
+        # many more than 50 draws to pin the reference's predictive mean/std tightly
+        n_ref = 2000
+        probs = np.zeros((n_ref, B, 2), np.float32)
+        with torch.no_grad():
+            for s in range(n_ref):
+                probs[s] = softmax(m(packed))
+        save(f"g5_mcstats_{model}", sd=sd_np(m), x=x, lengths=lengths,
+             mean=probs.mean(0).astype(np.float64), std=probs.std(0, ddof=1).astype(np.float64),
+             n_ref=np.int64(n_ref), S=np.int64(S), dropout=np.float32(st.dropout))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    oracle.build()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    if "g1" in which:
+        g1_vanilla()
+    if "g2" in which:
+        g2_variational()
+    if "g3" in which:
+        g3_bayesian()
+    if "g4" in which:
+        g4_train()
+    if "g5" in which:
+        g5_mc_stats()
