@@ -1,0 +1,183 @@
+/*
+ * snn_hip.h -- C ABI of libsnn_hip.so: the MI355X (gfx950) implementation of
+ * SuperNNova's RNN hot path (LSTM forward/backward x MC samples, Bayes-by-
+ * Backprop sampling + KL, variational masks, head + softmax, Adam).
+ *
+ * The reference is pure Python on PyTorch and has no FFI of its own; every
+ * entry point below replaces a *call site* of the reference, cited per
+ * function as <file>:<line> relative to the reference checkout.  The Python
+ * host layer (supernnova_amd/) binds these with ctypes and mirrors the
+ * reference's nn.Module API; see INTEGRATION.md for the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is owned by the caller
+ *     (the library never allocates device memory);
+ *   - all tensors fp32 contiguous, lengths/indices int32, offsets int64;
+ *   - every function returns 0 on success, a negative snn_status otherwise, and
+ *     never throws; snn_last_error() returns a thread-local message;
+ *   - launches are asynchronous on the given hipStream_t (passed as void*);
+ *     calls on different streams with different workspaces may overlap.
+ *
+ * Canonical flat parameter order ("flat", P floats) -- the order of torch's
+ * _flat_weights (torch.nn.LSTM) and of the eps draws in
+ * training/bayesian_rnn.py:472-528:
+ *   for layer l, for direction d:  w_ih (4H x I_l), w_hh (4H x H), b_ih (4H), b_hh (4H)
+ *   then head weight (C x F), head bias (C)
+ * with I_0 = D, I_l = dirs*H, F = dirs*H (pool mean) or dirs*H*L (pool standard).
+ * Gate order inside 4H is torch's (i, f, g, o).
+ */
+#ifndef SNN_HIP_H
+#define SNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum snn_status {
+    SNN_OK = 0,
+    SNN_ERR_ARG = -1,         /* bad argument (null pointer, negative size, ...) */
+    SNN_ERR_UNSUPPORTED = -2, /* configuration this build has no kernel for */
+    SNN_ERR_WORKSPACE = -3,   /* workspace too small */
+    SNN_ERR_HIP = -4          /* a HIP runtime call failed */
+} snn_status;
+
+#define SNN_POOL_MEAN 0     /* rnn_output_option == "mean"     (vanilla_rnn.py:74-83) */
+#define SNN_POOL_STANDARD 1 /* rnn_output_option == "standard" (vanilla_rnn.py:60-72) */
+
+/* settings the modules read: training/vanilla_rnn.py:9-16 */
+typedef struct snn_cfg {
+    int32_t input_size;    /* D  */
+    int32_t hidden_size;   /* H  (settings.hidden_dim) */
+    int32_t num_layers;    /* L  */
+    int32_t bidirectional; /* 0/1 */
+    int32_t nb_classes;    /* C  */
+    int32_t pool;          /* SNN_POOL_* */
+} snn_cfg;
+
+/* Prior of training/bayesian_rnn.py:753-763 (LSTM prior, then the head's). */
+typedef struct snn_prior {
+    float pi;
+    float sigma1, sigma2;         /* exp(log_sigma1), exp(log_sigma2)               */
+    float sigma1_out, sigma2_out; /* exp(log_sigma1_output), exp(log_sigma2_output) */
+} snn_prior;
+
+#define SNN_MASK_NONE 0   /* eval-mode vanilla, mean_field_inference=True             */
+#define SNN_MASK_ARRAYS 1 /* parity mode: masks drawn by the host in reference order  */
+#define SNN_MASK_PHILOX 2 /* sampled mode: Bernoulli masks from Philox4x32-10 in-kernel */
+
+/*
+ * Dropout masks of training/variational_rnn.py (values are 0 or 1/(1-p)), all
+ * indexed by the ORIGINAL curve index n in [0, n_curves):
+ *   in   (S, N, D)            locked input mask          :161-169 via :78-80
+ *   whh  (S, L, 4H)           W_hh row mask, forward direction only  :224-238
+ *   mid  (S, L-1, mid_T, N, dirs*H)  between layers; mid_T == 1 is the locked mask
+ *                             of :88-91, mid_T == max_T the per-step mask of
+ *                             torch.nn.LSTM(dropout=p) in train mode (vanilla_rnn.py:26-32)
+ *   out  (S, N, F)            output dropout             :138-140, 182-188
+ * Any pointer may be NULL (= no such mask).  In PHILOX mode the pointers are
+ * ignored and `which` selects the masks to draw (bit 0 in, 1 whh, 2 mid, 3 out).
+ */
+typedef struct snn_masks {
+    int32_t mode;  /* SNN_MASK_* */
+    int32_t which; /* PHILOX mode: bitmask of masks to draw */
+    int32_t mid_T; /* ARRAYS mode: 1 or max_T */
+    float keep_scale; /* PHILOX mode: 1/(1-p) as fp32 */
+    float keep_prob;  /* PHILOX mode: 1-p */
+    uint64_t seed;    /* PHILOX mode */
+    uint64_t offset;  /* PHILOX mode: draw counter of sample 0 (sample s uses offset+s) */
+    const float *in, *whh, *mid, *out;
+} snn_masks;
+
+const char *snn_last_error(void);
+int snn_version(void);
+
+/* ---- sizes (host only, no device access) -------------------------------- */
+int64_t snn_param_count(const snn_cfg *cfg);  /* P: canonical flat floats incl. head bias, <0 on error */
+int64_t snn_kparam_count(const snn_cfg *cfg); /* PK: floats of ONE weight set in kernel layout        */
+int32_t snn_feat(const snn_cfg *cfg);         /* F */
+int snn_supported(const snn_cfg *cfg);        /* 1 if this build has forward kernels for cfg          */
+
+/*
+ * Host-side batching plan; replaces the sort/pad bookkeeping of
+ * utils/training_utils.py:449-467 (argsort by length, descending) for ANY
+ * number of curves: curves are sorted by length (stable, descending) and cut
+ * into tiles of 32; tile i holds sorted positions [32i, 32i+32) and runs for
+ * tile_T[i] = its longest curve.  All outputs are HOST arrays:
+ *   order      (n_tiles*32) sorted position -> original index (-1 = padding)
+ *   len_sorted (n_tiles*32) length at sorted position (0 = padding)
+ *   tile_T     (n_tiles)
+ *   tile_off   (n_tiles+1)  float offset of each tile in the packed x buffer
+ *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D rounded up to even)
+ * n_tiles = ceil(n_curves/32).  Lengths must be >= 1.
+ */
+int snn_plan_build(const snn_cfg *cfg, const int32_t *lengths_host, int32_t n_curves,
+                   int32_t *order, int32_t *len_sorted, int32_t *tile_T, int64_t *tile_off);
+
+/*
+ * Pack padded light curves into the tile layout the LSTM kernel streams:
+ *   xp[tile_off[i] + (t*Dp + k)*32 + c] = x[t, order[32i+c], k]   (0 beyond the curve / padding)
+ * x is addressed as x[t*stride_t + n*stride_n + k]; (T,B,D) time-major has
+ * stride_t = B*D, stride_n = D (the X_tensor of utils/training_utils.py:454-461).
+ * order/len_sorted/tile_T/tile_off are DEVICE copies of the plan.
+ */
+int snn_pack_x(const snn_cfg *cfg, const float *x, int64_t stride_t, int64_t stride_n,
+               const int32_t *order, const int32_t *len_sorted, const int32_t *tile_T,
+               const int64_t *tile_off, int32_t n_tiles, int64_t xp_floats, float *xp, void *stream);
+
+/*
+ * Re-lay ONE canonical flat weight set (P floats) into kernel layout (PK
+ * floats).  Used for torch.nn.LSTM / nn.Linear weights of VanillaRNN and
+ * VariationalRNN (vanilla_rnn.py:26-34, variational_rnn.py:37-52).
+ */
+int snn_prepare_weights(const snn_cfg *cfg, const float *flat, float *wk, void *stream);
+
+/*
+ * Bayes-by-Backprop draw of S weight sets + their KL; replaces
+ * BayesLSTM.forward's sampling loop and BayesLinear.forward
+ * (training/bayesian_rnn.py:472-528, 595-616) and compute_KL (:794-815):
+ *   sigma = softplus(rho) + 1e-5;  w = mu + eps * sigma;  kl[s] = sum over the
+ *   4*L*dirs LSTM tensors and the head weight of  log q(w) - log p_mix(w).
+ *   mu  (P)      canonical flat, head bias (deterministic, :587-588) at the tail
+ *   rho (P - C)  canonical flat
+ *   eps (S, P-C) host-drawn N(0,1) in reference draw order (parity mode), or NULL
+ *   mode: 0 = use eps; 1 = mean_field_inference (w = mu, :486-488); 2 = Philox N(0,1)
+ *         keyed by (seed, offset + s, parameter index)
+ *   wk  (S, PK)  out: kernel-layout weights;  kl (S) out, may be NULL
+ *   kl_terms     scratch of S*(4*L*dirs+1) floats (caller-owned), may be NULL iff kl is NULL
+ */
+int snn_bbb_sample(const snn_cfg *cfg, const float *mu, const float *rho, const float *eps,
+                   int32_t mode, uint64_t seed, uint64_t offset, int32_t n_samples,
+                   const snn_prior *prior, float *wk, float *kl, float *kl_terms, void *stream);
+
+/* Bytes of workspace snn_lstm_forward needs for sequences up to max_T steps. */
+int64_t snn_lstm_forward_workspace_bytes(const snn_cfg *cfg, int32_t max_T);
+
+/*
+ * The hot path: LSTM stack + pooling + head + softmax for n_samples MC draws of
+ * every curve, one persistent launch.  Replaces the S sequential calls of
+ *   rnn.forward(X) -> softmax          validation/validate_rnn.py:59-60 (loop :319-331)
+ * i.e. torch.nn.LSTM / torch._VF.lstm at vanilla_rnn.py:47, variational_rnn.py:84,244,
+ * bayesian_rnn.py:530-553, the pooling of vanilla_rnn.py:60-83 and the output layer.
+ *   xp, len_sorted, order, tile_T, tile_off : from snn_plan_build / snn_pack_x (device)
+ *   wk : weight sets in kernel layout; set s is at wk + s*wk_sample_stride
+ *        (stride 0: all samples share one set -- vanilla / variational)
+ *   masks : NULL or dropout masks (see snn_masks)
+ *   out_logits / out_probs : either may be NULL; element (s, n, q) is written at
+ *        s*out_stride_sample + n*out_stride_curve + q with n the ORIGINAL curve index
+ */
+int snn_lstm_forward(const snn_cfg *cfg, const float *xp, const int32_t *len_sorted,
+                     const int32_t *order, const int32_t *tile_T, const int64_t *tile_off,
+                     int32_t n_curves, int32_t n_tiles, int32_t max_T, const float *wk,
+                     int64_t wk_sample_stride, int32_t n_samples, const snn_masks *masks,
+                     float *out_logits, float *out_probs, int64_t out_stride_sample,
+                     int64_t out_stride_curve, void *workspace, int64_t workspace_bytes,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNN_HIP_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libsnn_hip.so (the C ABI declared in include/snn_hip.h).
+
+The library is built in-tree by `make -C supernnova_amd/csrc` (or
+__graft_entry__.build()).  There is NO fallback: if the shared object is
+missing or fails to load, importing the kernels raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnn_hip.so")
+
+SNN_POOL_MEAN, SNN_POOL_STANDARD = 0, 1
+SNN_MASK_NONE, SNN_MASK_ARRAYS, SNN_MASK_PHILOX = 0, 1, 2
+BBB_EPS, BBB_MFE, BBB_PHILOX = 0, 1, 2
+TILE = 32
+
+
+class SnnCfg(ctypes.Structure):
+    _fields_ = [("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
+                ("num_layers", ctypes.c_int32), ("bidirectional", ctypes.c_int32),
+                ("nb_classes", ctypes.c_int32), ("pool", ctypes.c_int32)]
+
+
+class SnnPrior(ctypes.Structure):
+    _fields_ = [("pi", ctypes.c_float), ("sigma1", ctypes.c_float), ("sigma2", ctypes.c_float),
+                ("sigma1_out", ctypes.c_float), ("sigma2_out", ctypes.c_float)]
+
+
+class SnnMasks(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("which", ctypes.c_int32), ("mid_T", ctypes.c_int32),
+                ("keep_scale", ctypes.c_float), ("keep_prob", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+                ("m_in", ctypes.c_void_p), ("m_whh", ctypes.c_void_p),
+                ("m_mid", ctypes.c_void_p), ("m_out", ctypes.c_void_p)]
+
+
+class SnnError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+_CFG = ctypes.POINTER(SnnCfg)
+_I32P = ctypes.POINTER(ctypes.c_int32)
+_I64P = ctypes.POINTER(ctypes.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/snn_hip.h declares
+SIGNATURES = {
+    "snn_last_error": (ctypes.c_char_p, []),
+    "snn_version": (ctypes.c_int, []),
+    "snn_param_count": (ctypes.c_int64, [_CFG]),
+    "snn_kparam_count": (ctypes.c_int64, [_CFG]),
+    "snn_feat": (ctypes.c_int32, [_CFG]),
+    "snn_supported": (ctypes.c_int, [_CFG]),
+    "snn_plan_build": (ctypes.c_int, [_CFG, _I32P, ctypes.c_int32, _I32P, _I32P, _I32P, _I64P]),
+    "snn_pack_x": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P,
+                                  ctypes.c_int32, ctypes.c_int64, _P, _P]),
+    "snn_prepare_weights": (ctypes.c_int, [_CFG, _P, _P, _P]),
+    "snn_bbb_sample": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
+                                      ctypes.c_int32, ctypes.POINTER(SnnPrior), _P, _P, _P, _P]),
+    "snn_lstm_forward_workspace_bytes": (ctypes.c_int64, [_CFG, ctypes.c_int32]),
+    "snn_lstm_forward": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64,
+                                        _P, ctypes.c_int64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsnn_hip.so; raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(`make -C supernnova_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "supernnova_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = load().snn_last_error()
+        raise SnnError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

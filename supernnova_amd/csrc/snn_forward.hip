@@ -1,0 +1,837 @@
+// snn_forward.hip -- gfx950 kernels + C ABI for the inference hot path:
+//   pack_x_kernel      light curves -> 32-curve tiles in MFMA B-operand order
+//   bbb_sample_kernel  w = mu + eps*softplus(rho) into kernel layout, + KL sums
+//   lstm_fwd_kernel    persistent LSTM stack + pooling + head + softmax
+// See include/snn_hip.h for the contract and the reference call sites replaced.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "../../include/snn_hip.h"
+#include "snn_device.h"
+#include "snn_layout.h"
+#include "snn_host.h"
+
+// ============================================================================
+// pack_x: one workgroup per tile, one thread per (t, curve), loop over features
+// ============================================================================
+__global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float* __restrict__ x,
+                                                    int64_t stride_t, int64_t stride_n,
+                                                    const int32_t* __restrict__ order,
+                                                    const int32_t* __restrict__ len_sorted,
+                                                    const int32_t* __restrict__ tile_T,
+                                                    const int64_t* __restrict__ tile_off,
+                                                    float* __restrict__ xp)
+{
+    const int tile = blockIdx.x;
+    const int T = tile_T[tile];
+    float* dst = xp + tile_off[tile];
+    for (int idx = threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x) {
+        const int t = idx >> 5, c = idx & 31;
+        const int pos = tile * SNN_TILE + c;
+        const int orig = order[pos];
+        const bool live = orig >= 0 && t < len_sorted[pos];
+        const float* src = x + (int64_t)t * stride_t + (int64_t)(live ? orig : 0) * stride_n;
+        float* o = dst + (int64_t)t * Dp * SNN_TILE + c;
+        for (int k = 0; k < Dp; ++k) o[(int64_t)k * SNN_TILE] = (live && k < D) ? src[k] : 0.0f;
+    }
+}
+
+// ============================================================================
+// Bayes-by-Backprop sampling + KL (also the plain re-layout when rho == NULL)
+// ============================================================================
+struct TensorGeom {
+    int64_t cbase;  // canonical offset
+    int64_t n;      // elements
+    int cols;       // row length (1 for biases)
+    int kind;       // 0 w_ih, 1 w_hh, 2 b_ih, 3 b_hh, 4 head w, 5 head b
+    int ld;
+};
+
+__device__ __forceinline__ TensorGeom tensor_geom(const SnnLayout& y, int tau)
+{
+    TensorGeom g;
+    const int nld = y.L * y.dirs;
+    if (tau < 4 * nld) {
+        g.ld = tau >> 2;
+        g.kind = tau & 3;
+        const int l = g.ld / y.dirs;
+        if (g.kind == 0) { g.cbase = y.c_wih[g.ld]; g.cols = y.I[l]; g.n = (int64_t)4 * y.H * y.I[l]; }
+        else if (g.kind == 1) { g.cbase = y.c_whh[g.ld]; g.cols = y.H; g.n = (int64_t)4 * y.H * y.H; }
+        else if (g.kind == 2) { g.cbase = y.c_bih[g.ld]; g.cols = 1; g.n = 4 * y.H; }
+        else { g.cbase = y.c_bhh[g.ld]; g.cols = 1; g.n = 4 * y.H; }
+    } else if (tau == 4 * nld) {
+        g.ld = 0; g.kind = 4; g.cbase = y.c_head_w; g.cols = y.F; g.n = (int64_t)y.C * y.F;
+    } else {
+        g.ld = 0; g.kind = 5; g.cbase = y.c_head_b; g.cols = 1; g.n = y.C;
+    }
+    return g;
+}
+
+// canonical element i of tensor g -> index in the kernel layout
+__device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const TensorGeom& g, int64_t i)
+{
+    if (g.kind == 4) return y.k_head_w + i;
+    if (g.kind == 5) return y.k_head_b + i;
+    const int l = g.ld / y.dirs;
+    const int H = y.H;
+    if (g.kind <= 1) {
+        const int R = (int)(i / g.cols), col = (int)(i - (int64_t)R * g.cols);
+        const int gate = R / H, j = R - gate * H;
+        const int w = j >> 3, r = gate * 8 + (j & 7);
+        const int k = g.kind == 0 ? col : 2 * y.KKI[l] + col;
+        const int kk = k >> 1, lane = (k & 1) * 32 + r;
+        return y.k_A[g.ld] + ((int64_t)(w * y.KK[l] + kk)) * 64 + lane;
+    }
+    const int R = (int)i, gate = R / H, j = R - gate * H;
+    const int w = j >> 3, hf = (j & 7) >> 2, ii = gate * 4 + (j & 3);
+    return y.k_bias[g.ld] + (g.kind == 3 ? y.NW * 32 : 0) + (w * 2 + hf) * 16 + ii;
+}
+
+__device__ __forceinline__ float softplus_f(float r) { return r > 20.0f ? r : log1pf(expf(r)); }
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+    return s;
+}
+
+__global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
+                                                        const float* __restrict__ rho,
+                                                        const float* __restrict__ eps, int mode,
+                                                        uint64_t seed, uint64_t offset, snn_prior prior,
+                                                        float* __restrict__ wk, float* __restrict__ kl_terms)
+{
+    __shared__ double sh[4];
+    const int tau = blockIdx.x, s = blockIdx.y;
+    const TensorGeom g = tensor_geom(y, tau);
+    const int64_t Ps = y.P - y.C;
+    float* dst = wk + (int64_t)s * y.PK;
+    const bool sampled = rho != nullptr && g.kind != 5;
+    const bool want_kl = kl_terms != nullptr && sampled;
+    const float lsq = 0.91893853320467274f;  // log(sqrt(2 pi))
+    const float s1 = g.kind == 4 ? prior.sigma1_out : prior.sigma1;
+    const float s2 = g.kind == 4 ? prior.sigma2_out : prior.sigma2;
+    const float v1 = s1 * s1, v2 = s2 * s2, l1 = logf(s1), l2 = logf(s2);
+    double q = 0, p1 = 0, p2 = 0;
+    for (int64_t i = threadIdx.x; i < g.n; i += blockDim.x) {
+        const int64_t p = g.cbase + i;
+        const float m = mu[p];
+        float w = m;
+        if (sampled) {
+            const float sg = softplus_f(rho[p]) + 1e-5f;
+            if (mode != 1) {
+                const float e = mode == 0 ? eps[(int64_t)s * Ps + p]
+                                          : philox_normal(seed, offset + s, SNN_STREAM_BBB, (uint64_t)p);
+                w = __fadd_rn(m, __fmul_rn(e, sg));  // two roundings, as torch's mul then add
+            }
+            if (want_kl) {
+                // torch.distributions.Normal.log_prob, element-wise in fp32 (bayesian_rnn.py:796-811)
+                const float d = w - m;
+                const float var = sg * sg;
+                q += (double)(__fdiv_rn(-(d * d), 2.0f * var) - logf(sg) - lsq);
+                const float x2 = w * w;
+                p1 += (double)(__fdiv_rn(-x2, 2.0f * v1) - l1 - lsq);
+                p2 += (double)(__fdiv_rn(-x2, 2.0f * v2) - l2 - lsq);
+            }
+        }
+        dst[kernel_index(y, g, i)] = w;
+    }
+    if (kl_terms != nullptr && g.kind != 5) {
+        q = block_sum(q, sh);
+        p1 = block_sum(p1, sh);
+        p2 = block_sum(p2, sh);
+        if (threadIdx.x == 0) {
+            float term = 0.0f;
+            if (sampled) {
+                const float m1 = (float)p1 + logf(prior.pi), m2 = (float)p2 + logf(1.0f - prior.pi);
+                const float mx = fmaxf(m1, m2);
+                const float lse = mx + logf(expf(m1 - mx) + expf(m2 - mx));
+                term = (float)q - lse;
+            }
+            kl_terms[(int64_t)s * y.n_tensors + tau] = term;
+        }
+    }
+}
+
+// kl[s] = fp32 running sum over tensors in reference order (bayesian_rnn.py:501-528, 137)
+__global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ terms, float* __restrict__ kl)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float acc = 0.0f;
+    for (int t = 0; t < n_tensors; ++t) acc = __fadd_rn(acc, terms[(int64_t)s * n_tensors + t]);
+    kl[s] = acc;
+}
+
+// ============================================================================
+// Persistent LSTM forward
+// ============================================================================
+struct FwdParams {
+    int D, L, C, pool, F;
+    const float* xp;
+    const int32_t* len_sorted;
+    const int32_t* order;
+    const int32_t* tile_T;
+    const int64_t* tile_off;
+    int n_curves, n_tiles, max_T, n_samples;
+    const float* wk;
+    int64_t wk_stride;
+    // masks
+    int mask_mode, mask_which, mid_T;
+    float keep_scale, keep_prob;
+    uint64_t seed, offset;
+    const float *m_in, *m_whh, *m_mid, *m_out;
+    // outputs
+    float* out_logits;
+    float* out_probs;
+    int64_t os_s, os_n;
+    // workspace
+    unsigned int* counter;
+    float* yscratch;       // [grid][nbuf][dirs][max_T][H*32]
+    int64_t y_buf_floats;  // dirs*max_T*H*32
+    int nbuf;
+};
+
+// LDS-only barrier: global stores of the step stay in flight (they are only
+// read after the phase-end __syncthreads()).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int H, int KKI, int DIRS>
+struct PhaseCfg {
+    static constexpr int NT = H * 8;                 // threads per workgroup
+    static constexpr int ROWS = 2 * KKI;             // input rows staged per step
+    static constexpr int NF4 = ROWS * 8;             // float4 per step
+    static constexpr int NPT = (NF4 + NT - 1) / NT;  // float4 per thread per step
+};
+
+struct ItemCtx {
+    int tile, s, T, w, lane, cl, hf, tid;
+    int len, orig;          // of this lane's curve
+    const float* wks;       // weight set of this sample
+    float* ybase;           // this workgroup's y scratch
+};
+
+// One (layer, direction) pass over the tile's T steps.
+//   FIRST: input comes from the packed x tile; else from the previous layer's y buffer.
+template <int H, int KKI, int DIRS, bool FIRST>
+__device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, float* smem, int l, int d,
+                                          int k_A, int k_bias, int k_head_w, float* xin, float* hb, float* part,
+                                          float* logit)
+{
+    using PC = PhaseCfg<H, KKI, DIRS>;
+    constexpr int NT = PC::NT, NPT = PC::NPT, NF4 = PC::NF4, KKH = H / 2, KK = KKI + KKH;
+    constexpr int XIN_STRIDE = PC::ROWS * 32;  // floats per xin buffer for this phase
+    const FwdParams& y = p;  // D, L, C, pool, F
+    const int ld = l * DIRS + d;
+    const bool last_layer = l == y.L - 1;
+    const int T = c.T;
+    (void)smem;
+    constexpr int NW = H / 8;
+
+    // ---- weights -> registers (A operand of every MFMA of this phase)
+    float wreg[KK];
+    {
+        const float* A = c.wks + k_A + c.w * KK * 64 + c.lane;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];
+    }
+    // variational W_hh row mask: forward direction only (variational_rnn.py:45, 224-238)
+    if (d == 0 && p.mask_mode != SNN_MASK_NONE) {
+        const int r = c.lane & 31;
+        const int R = (r >> 3) * H + 8 * c.w + (r & 7);
+        float m = 1.0f;
+        if (p.mask_mode == SNN_MASK_ARRAYS) {
+            if (p.m_whh) m = p.m_whh[((int64_t)c.s * y.L + l) * 4 * H + R];
+        } else if (p.mask_which & 2) {
+            m = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_WHH, (uint32_t)R, (uint32_t)l, p.keep_prob,
+                            p.keep_scale);
+        }
+#pragma unroll
+        for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
+    }
+    f32x16 binit;
+    {
+        const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) binit[i] = B[i] + B[NW * 32 + i];
+    }
+
+    // ---- per-lane masks
+    const int j0 = 8 * c.w + 4 * c.hf;  // first of this lane's 4 hidden units
+    float mmid[4] = {1.f, 1.f, 1.f, 1.f};
+    bool mid_step = false;
+    if (!last_layer && p.mask_mode != SNN_MASK_NONE && c.orig >= 0) {
+        if (p.mask_mode == SNN_MASK_ARRAYS) {
+            if (p.m_mid) {
+                if (p.mid_T > 1) mid_step = true;
+                else {
+                    const float* M = p.m_mid + (((int64_t)c.s * (y.L - 1) + l) * p.n_curves + c.orig) * (DIRS * H) + d * H + j0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mmid[u] = M[u];
+                }
+            }
+        } else if (p.mask_which & 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                mmid[u] = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_MID, (uint32_t)c.orig,
+                                      (uint32_t)(l * DIRS * H + d * H + j0 + u), p.keep_prob, p.keep_scale);
+        }
+    }
+    // input-mask registers of the staging threads (layer 0 only)
+    float min_[NPT][4];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
+    if (FIRST && p.mask_mode != SNN_MASK_NONE) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                const int k = f >> 3, c4 = (f & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                    if (o >= 0 && k < y.D) {
+                        if (p.mask_mode == SNN_MASK_ARRAYS) {
+                            if (p.m_in) min_[i][e] = p.m_in[((int64_t)c.s * p.n_curves + o) * y.D + k];
+                        } else if (p.mask_which & 1) {
+                            min_[i][e] = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_IN, (uint32_t)o,
+                                                     (uint32_t)k, p.keep_prob, p.keep_scale);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- input source
+    const float* in0;  // FIRST: tile base; else y buffer of layer l-1
+    if (FIRST) in0 = p.xp + p.tile_off[c.tile];
+    else in0 = c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
+    float* yout = last_layer ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+
+    auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                const float* src;
+                if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
+                else {
+                    const int dd = f / (H * 8), ff = f - dd * (H * 8);
+                    src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
+                }
+                pre[i] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT]) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                f32x4 v = pre[i];
+                if (FIRST) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                }
+                *reinterpret_cast<f32x4*>(dstbuf + f * 4) = v;
+            }
+        }
+    };
+
+    // ---- state
+    float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f}, hsum[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 pre[NPT];
+        load_step(d == 0 ? 0 : T - 1, pre);
+        store_step(xin, pre);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hb[(j0 + u) * 32 + c.cl] = 0.0f;
+    }
+    lds_barrier();
+
+    for (int step = 0; step < T; ++step) {
+        const int t = d == 0 ? step : T - 1 - step;
+        const int cur = step & 1;
+        f32x4 pre[NPT];
+        const bool more = step + 1 < T;
+        if (more) load_step(d == 0 ? t + 1 : t - 1, pre);
+
+        f32x16 acc = binit;
+        const float* xc = xin + cur * XIN_STRIDE + c.lane;
+#pragma unroll
+        for (int kk = 0; kk < KKI; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], xc[kk * 64], acc, 0, 0, 0);
+        const float* hc = hb + cur * (H * 32) + c.lane;
+#pragma unroll
+        for (int kk = 0; kk < KKH; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[KKI + kk], hc[kk * 64], acc, 0, 0, 0);
+
+        const bool valid = t < c.len;
+        float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
+        float outv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ig = snn_sigmoid(acc[u]);
+            const float fg = snn_sigmoid(acc[4 + u]);
+            const float gg = snn_tanh(acc[8 + u]);
+            const float og = snn_sigmoid(acc[12 + u]);
+            const float cn = fg * cst[u] + ig * gg;
+            const float hv = og * snn_tanh(cn);
+            cst[u] = valid ? cn : cst[u];
+            hst[u] = valid ? hv : hst[u];
+            outv[u] = valid ? hv : 0.0f;
+            hn[u * 32] = hst[u];
+        }
+        if (last_layer) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hsum[u] += outv[u];
+        } else {
+            float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
+            if (mid_step && c.orig >= 0) {
+                const float* M = p.m_mid + ((((int64_t)c.s * (y.L - 1) + l) * p.mid_T + t) * p.n_curves + c.orig) * (DIRS * H) + d * H + j0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(M[u], outv[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mmid[u], outv[u]);
+            }
+        }
+        if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre);
+        lds_barrier();
+    }
+
+    // ---- head contribution of this phase
+    const bool contributes = y.pool == SNN_POOL_STANDARD || last_layer;
+    if (contributes) {
+        float feat[4];
+        int fidx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (y.pool == SNN_POOL_MEAN) {
+                feat[u] = __fdiv_rn(hsum[u], (float)(c.len > 0 ? c.len : 1));
+                fidx[u] = d * H + j0 + u;
+            } else {
+                feat[u] = hst[u];
+                fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
+            }
+        }
+        if (p.mask_mode != SNN_MASK_NONE && c.orig >= 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float m = 1.0f;
+                if (p.mask_mode == SNN_MASK_ARRAYS) {
+                    if (p.m_out) m = p.m_out[((int64_t)c.s * p.n_curves + c.orig) * y.F + fidx[u]];
+                } else if (p.mask_which & 8) {
+                    m = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_OUT, (uint32_t)c.orig, (uint32_t)fidx[u],
+                                    p.keep_prob, p.keep_scale);
+                }
+                feat[u] = __fmul_rn(m, feat[u]);
+            }
+        }
+        const float* Wo = c.wks + k_head_w;
+        for (int q = 0; q < y.C; ++q) {
+            float a = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a = fmaf(Wo[q * y.F + fidx[u]], feat[u], a);
+            a += __shfl_xor(a, 32);
+            if (c.hf == 0) part[(c.w * y.C + q) * 32 + c.cl] = a;
+        }
+        __syncthreads();
+        for (int idx = c.tid; idx < y.C * 32; idx += NT) {
+            const int q = idx >> 5, cc = idx & 31;
+            float a = logit[idx];
+            for (int w = 0; w < H / 8; ++w) a += part[(w * y.C + q) * 32 + cc];
+            logit[idx] = a;
+        }
+    }
+    __syncthreads();  // also publishes this phase's y stores to the workgroup
+}
+
+template <int H, int KKI0, int DIRS>
+__global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
+{
+    constexpr int NT = H * 8;
+    constexpr int KKI1 = DIRS * H / 2;
+    constexpr int ROWS = (2 * KKI0 > 2 * KKI1) ? 2 * KKI0 : 2 * KKI1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdParams& y = p;
+    // kernel-layout offsets of snn_layout.h, compile-time given the template parameters
+    constexpr int NW = H / 8;
+    constexpr int BLK0 = NW * (KKI0 + H / 2) * 64 + 2 * NW * 32;  // one (layer 0, dir) block
+    constexpr int BLK1 = NW * (KKI1 + H / 2) * 64 + 2 * NW * 32;  // one (layer >= 1, dir) block
+    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
+    float* xin = smem;                      // [2][ROWS*32]
+    float* hb = xin + 2 * ROWS * 32;        // [2][H*32]
+    float* part = hb + 2 * H * 32;          // [NW][C][32]
+    float* logit = part + (H / 8) * y.C * 32;  // [C][32]
+    int* item_slot = reinterpret_cast<int*>(logit + y.C * 32);
+
+    ItemCtx c;
+    c.tid = threadIdx.x;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.cl = c.lane & 31;
+    c.hf = c.lane >> 5;
+    c.ybase = p.yscratch + (int64_t)blockIdx.x * p.nbuf * p.y_buf_floats;
+    const int64_t n_items = (int64_t)p.n_tiles * p.n_samples;
+
+    for (;;) {
+        if (c.tid == 0) *item_slot = (int)atomicAdd(p.counter, 1u);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(*item_slot);
+        if (item >= n_items) break;
+        c.tile = item / p.n_samples;
+        c.s = item - c.tile * p.n_samples;
+        c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+        const int pos = c.tile * SNN_TILE + c.cl;
+        c.len = p.len_sorted[pos];
+        c.orig = p.order[pos];
+        c.wks = p.wk + (int64_t)c.s * p.wk_stride;
+        for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
+        __syncthreads();  // item_slot consumed, logit zeroed
+
+        for (int l = 0; l < y.L; ++l) {
+            for (int d = 0; d < DIRS; ++d) {
+                if (l == 0) {
+                    const int kA = d * BLK0;
+                    run_phase<H, KKI0, DIRS, true>(p, c, smem, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin,
+                                                   hb, part, logit);
+                } else {
+                    const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
+                    run_phase<H, KKI1, DIRS, false>(p, c, smem, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin,
+                                                    hb, part, logit);
+                }
+            }
+        }
+
+        // ---- head bias + softmax, one thread per curve
+        if (c.tid < 32) {
+            const int orig = c.orig;  // tid < 32: lane == cl
+            if (orig >= 0) {
+                const float* bo = c.wks + k_head_w + y.C * y.F;
+                float mx = -INFINITY;
+                for (int q = 0; q < y.C; ++q) mx = fmaxf(mx, logit[q * 32 + c.tid] + bo[q]);
+                float z = 0.0f;
+                for (int q = 0; q < y.C; ++q) z += expf(logit[q * 32 + c.tid] + bo[q] - mx);
+                const int64_t o = (int64_t)c.s * p.os_s + (int64_t)orig * p.os_n;
+                for (int q = 0; q < y.C; ++q) {
+                    const float lg = logit[q * 32 + c.tid] + bo[q];
+                    if (p.out_logits) p.out_logits[o + q] = lg;
+                    if (p.out_probs) p.out_probs[o + q] = __fdiv_rn(expf(lg - mx), z);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ============================================================================
+// host side
+// ============================================================================
+static thread_local char g_err[512] = "";
+void snn_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* snn_last_error(void) { return g_err; }
+extern "C" int snn_version(void) { return 100; }
+
+int snn_make_layout(const snn_cfg* cfg, SnnLayout* y)
+{
+    if (!cfg) { snn_set_error("cfg is NULL"); return SNN_ERR_ARG; }
+    if (snn_layout_init(y, cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->bidirectional,
+                        cfg->nb_classes, cfg->pool) != 0) {
+        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d (need H %% 8 == 0, 1 <= L <= %d)", cfg->input_size,
+                      cfg->hidden_size, cfg->num_layers, cfg->nb_classes, cfg->pool, SNN_MAX_LAYERS);
+        return SNN_ERR_ARG;
+    }
+    return SNN_OK;
+}
+
+extern "C" int64_t snn_param_count(const snn_cfg* cfg)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    return rc ? rc : y.P;
+}
+extern "C" int64_t snn_kparam_count(const snn_cfg* cfg)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    return rc ? rc : y.PK;
+}
+extern "C" int32_t snn_feat(const snn_cfg* cfg)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    return rc ? rc : y.F;
+}
+
+// ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
+typedef void (*fwd_kernel_t)(const FwdParams);
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn; };
+#define FWD_ENTRY(H, K, Dd) {H, K, Dd, lstm_fwd_kernel<H, K, Dd>}
+static const FwdEntry g_fwd[] = {
+    FWD_ENTRY(32, 12, 2),  // D = 23..24  (4 filters)
+    FWD_ENTRY(32, 13, 2),  // D = 25..26  (4 filters + redshift)
+    FWD_ENTRY(32, 12, 1),
+    FWD_ENTRY(64, 12, 2),
+    FWD_ENTRY(64, 13, 2),
+};
+static const FwdEntry* find_fwd(const SnnLayout& y)
+{
+    for (const FwdEntry& e : g_fwd)
+        if (e.H == y.H && e.KKI0 == y.KKI[0] && e.dirs == y.dirs) return &e;
+    return nullptr;
+}
+extern "C" int snn_supported(const snn_cfg* cfg)
+{
+    SnnLayout y;
+    if (snn_make_layout(cfg, &y)) return 0;
+    return find_fwd(y) != nullptr;
+}
+
+extern "C" int snn_plan_build(const snn_cfg* cfg, const int32_t* lengths, int32_t n, int32_t* order,
+                              int32_t* len_sorted, int32_t* tile_T, int64_t* tile_off)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (!lengths || !order || !len_sorted || !tile_T || !tile_off || n < 1) {
+        snn_set_error("snn_plan_build: null pointer or n_curves < 1");
+        return SNN_ERR_ARG;
+    }
+    // counting sort by length, descending, stable
+    int32_t maxlen = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (lengths[i] < 1) { snn_set_error("snn_plan_build: lengths[%d] = %d < 1", i, lengths[i]); return SNN_ERR_ARG; }
+        maxlen = std::max(maxlen, lengths[i]);
+    }
+    std::vector<int64_t> start((size_t)maxlen + 2, 0);
+    for (int32_t i = 0; i < n; ++i) start[(size_t)(maxlen - lengths[i]) + 1]++;
+    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+    const int32_t n_tiles = (n + SNN_TILE - 1) / SNN_TILE;
+    for (int64_t i = n; i < (int64_t)n_tiles * SNN_TILE; ++i) { order[i] = -1; len_sorted[i] = 0; }
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t pos = start[(size_t)(maxlen - lengths[i])]++;
+        order[pos] = i;
+        len_sorted[pos] = lengths[i];
+    }
+    int64_t off = 0;
+    for (int32_t t = 0; t < n_tiles; ++t) {
+        tile_T[t] = len_sorted[(int64_t)t * SNN_TILE];
+        tile_off[t] = off;
+        off += (int64_t)tile_T[t] * y.Dp * SNN_TILE;
+    }
+    tile_off[n_tiles] = off;
+    return SNN_OK;
+}
+
+#define HIP_CHECK(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            snn_set_error("%s failed: %s", #expr, hipGetErrorString(e_));           \
+            return SNN_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, int64_t stride_n,
+                          const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
+                          const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp, void* stream)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (!x || !order || !len_sorted || !tile_T || !tile_off || !xp || n_tiles < 1 || xp_floats < 0) {
+        snn_set_error("snn_pack_x: null pointer or bad size");
+        return SNN_ERR_ARG;
+    }
+    (void)xp_floats;
+    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
+                       stride_n, order, len_sorted, tile_T, tile_off, xp);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
+}
+
+static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, const float* eps, int mode,
+                         uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
+                         float* kl_terms, hipStream_t st)
+{
+    if (y.PK != y.k_head_b + y.C || (y.D & 1))  // padding floats exist: define them
+        HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
+    hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
+                       offset, prior, wk, kl ? kl_terms : nullptr);
+    HIP_CHECK(hipGetLastError());
+    if (kl) {
+        hipLaunchKernelGGL(kl_sum_kernel, dim3((S + 63) / 64), dim3(64), 0, st, y.n_tensors, S, kl_terms, kl);
+        HIP_CHECK(hipGetLastError());
+    }
+    return SNN_OK;
+}
+
+extern "C" int snn_prepare_weights(const snn_cfg* cfg, const float* flat, float* wk, void* stream)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (!flat || !wk) { snn_set_error("snn_prepare_weights: null pointer"); return SNN_ERR_ARG; }
+    snn_prior pr = {0.5f, 1.f, 1.f, 1.f, 1.f};
+    return launch_sample(y, flat, nullptr, nullptr, 1, 0, 0, 1, pr, wk, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* rho, const float* eps, int32_t mode,
+                              uint64_t seed, uint64_t offset, int32_t S, const snn_prior* prior, float* wk,
+                              float* kl, float* kl_terms, void* stream)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (!mu || !rho || !wk || !prior || S < 1 || S > 65535) {
+        snn_set_error("snn_bbb_sample: null pointer or n_samples out of [1, 65535]");
+        return SNN_ERR_ARG;
+    }
+    if (mode < 0 || mode > 2 || (mode == 0 && !eps)) {
+        snn_set_error("snn_bbb_sample: mode %d invalid or eps missing", mode);
+        return SNN_ERR_ARG;
+    }
+    if (kl && !kl_terms) { snn_set_error("snn_bbb_sample: kl requested without kl_terms scratch"); return SNN_ERR_ARG; }
+    if (!(prior->pi > 0.f && prior->pi < 1.f) || !(prior->sigma1 > 0.f) || !(prior->sigma2 > 0.f) ||
+        !(prior->sigma1_out > 0.f) || !(prior->sigma2_out > 0.f)) {
+        snn_set_error("snn_bbb_sample: prior out of range");
+        return SNN_ERR_ARG;
+    }
+    return launch_sample(y, mu, rho, eps, mode, seed, offset, S, *prior, wk, kl, kl_terms, (hipStream_t)stream);
+}
+
+// ---- persistent forward launch geometry ------------------------------------
+struct FwdGeom { int grid, nbuf; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
+
+static int fwd_geom(const SnnLayout& y, const FwdEntry* e, int max_T, FwdGeom* g)
+{
+    const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
+    g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
+    if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cached_cus = prop.multiProcessorCount;
+        cached_dev = dev;
+    }
+    int per_cu = 0;
+    HIP_CHECK(hipFuncSetAttribute((const void*)e->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)e->fn, y.H * 8, g->lds));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    g->grid = cached_cus * per_cu;
+    g->nbuf = y.L > 2 ? 2 : 1;
+    g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32;
+    g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
+    return SNN_OK;
+}
+
+extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t max_T)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    const FwdEntry* e = find_fwd(y);
+    if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
+    FwdGeom g;
+    rc = fwd_geom(y, e, max_T, &g);
+    return rc ? rc : g.ws_bytes;
+}
+
+extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
+                                const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
+                                int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
+                                int64_t wk_sample_stride, int32_t n_samples, const snn_masks* masks,
+                                float* out_logits, float* out_probs, int64_t out_stride_sample,
+                                int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    const FwdEntry* e = find_fwd(y);
+    if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !workspace || (!out_logits && !out_probs)) {
+        snn_set_error("snn_lstm_forward: null pointer");
+        return SNN_ERR_ARG;
+    }
+    if (n_curves < 1 || n_tiles != (n_curves + SNN_TILE - 1) / SNN_TILE || max_T < 1 || n_samples < 1 ||
+        (int64_t)n_tiles * n_samples > 0x7fffffff || wk_sample_stride < 0 ||
+        (wk_sample_stride != 0 && wk_sample_stride < y.PK)) {
+        snn_set_error("snn_lstm_forward: inconsistent sizes (n_curves=%d n_tiles=%d max_T=%d n_samples=%d)", n_curves,
+                      n_tiles, max_T, n_samples);
+        return SNN_ERR_ARG;
+    }
+    FwdGeom g;
+    rc = fwd_geom(y, e, max_T, &g);
+    if (rc) return rc;
+    if (workspace_bytes < g.ws_bytes) {
+        snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
+        return SNN_ERR_WORKSPACE;
+    }
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.D = y.D; p.L = y.L; p.C = y.C; p.pool = y.pool; p.F = y.F;
+    p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
+    p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
+    p.wk = wk; p.wk_stride = wk_sample_stride;
+    if (masks && masks->mode != SNN_MASK_NONE) {
+        if (masks->mode == SNN_MASK_ARRAYS) {
+            if (masks->mid && masks->mid_T != 1 && masks->mid_T != max_T) {
+                snn_set_error("snn_lstm_forward: masks.mid_T must be 1 or max_T");
+                return SNN_ERR_ARG;
+            }
+        } else if (masks->mode == SNN_MASK_PHILOX) {
+            if (!(masks->keep_prob > 0.f && masks->keep_prob <= 1.f)) {
+                snn_set_error("snn_lstm_forward: masks.keep_prob out of (0,1]");
+                return SNN_ERR_ARG;
+            }
+        } else {
+            snn_set_error("snn_lstm_forward: masks.mode %d invalid", masks->mode);
+            return SNN_ERR_ARG;
+        }
+        p.mask_mode = masks->mode; p.mask_which = masks->which; p.mid_T = masks->mid ? masks->mid_T : 1;
+        p.keep_scale = masks->keep_scale; p.keep_prob = masks->keep_prob; p.seed = masks->seed; p.offset = masks->offset;
+        p.m_in = masks->in; p.m_whh = masks->whh; p.m_mid = masks->mid; p.m_out = masks->out;
+    }
+    p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
+    p.counter = (unsigned int*)workspace;
+    p.yscratch = (float*)((char*)workspace + 256);
+    p.y_buf_floats = g.y_buf_floats;
+    p.nbuf = g.nbuf;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
+    const int64_t n_items = (int64_t)n_tiles * n_samples;
+    const int grid = (int)std::min<int64_t>(g.grid, n_items);
+    hipLaunchKernelGGL(e->fn, dim3(grid), dim3(y.H * 8), g.lds, st, p);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
+}

@@ -1,0 +1,70 @@
+// snn_layout.h -- parameter layouts shared by host code and kernels.
+//
+// Canonical flat order (torch _flat_weights; eps draw order of the reference,
+// training/bayesian_rnn.py:472-528): per (layer, dir) w_ih, w_hh, b_ih, b_hh;
+// then head weight, head bias.
+//
+// Kernel layout of one weight set (what the persistent LSTM kernel loads
+// straight into MFMA A-operand registers):
+//   per (layer, dir):
+//     A image  [NW][KK][64]   A[w][kk][lane] = Wcat[row(w, lane&31)][2*kk + (lane>>5)]
+//              Wcat = [w_ih | zero pad to even | w_hh] (4H x (2*KKI + H)),
+//              row(w, r) = (r>>3)*H + 8*w + (r&7)   (gate r>>3 of hidden unit 8w + (r&7)),
+//              so the 32x32 MFMA tile of wave w holds the 4 gates of 8 units and each
+//              lane of the C/D tile ends up with all 4 gates of 4 units;
+//     bias image [2][NW][2][16]  (b_ih then b_hh) in C/D register order:
+//              entry (w, hf, i) = bias[(i>>2)*H + 8*w + 4*hf + (i&3)]
+//   then head weight (C x F) and head bias (C), canonical.
+#pragma once
+#include <stdint.h>
+
+#define SNN_MAX_LAYERS 4
+#define SNN_MAX_LD (2 * SNN_MAX_LAYERS)
+#define SNN_TILE 32
+
+struct SnnLayout {
+    int D, H, L, dirs, C, pool, F;
+    int Dp;  // D rounded up to even
+    int NW;  // waves per workgroup = H / 8
+    int I[SNN_MAX_LAYERS];    // input width of layer l
+    int KKI[SNN_MAX_LAYERS];  // ceil(I/2): MFMA k-steps of the input part
+    int KK[SNN_MAX_LAYERS];   // KKI + H/2
+    int64_t c_wih[SNN_MAX_LD], c_whh[SNN_MAX_LD], c_bih[SNN_MAX_LD], c_bhh[SNN_MAX_LD];
+    int64_t k_A[SNN_MAX_LD], k_bias[SNN_MAX_LD];
+    int64_t c_head_w, c_head_b, k_head_w, k_head_b;
+    int64_t P, PK;
+    int n_tensors;  // sampled tensors: 4*L*dirs + 1
+};
+
+static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool)
+{
+    if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1)
+        return -1;
+    y->D = D; y->H = H; y->L = L; y->dirs = bidir ? 2 : 1; y->C = C; y->pool = pool;
+    y->F = pool == 0 ? y->dirs * H : y->dirs * H * L;
+    y->Dp = (D + 1) & ~1;
+    y->NW = H / 8;
+    int64_t c = 0, k = 0;
+    for (int l = 0; l < L; ++l) {
+        y->I[l] = l == 0 ? D : y->dirs * H;
+        y->KKI[l] = (y->I[l] + 1) / 2;
+        y->KK[l] = y->KKI[l] + H / 2;
+        for (int d = 0; d < y->dirs; ++d) {
+            int ld = l * y->dirs + d;
+            y->c_wih[ld] = c; c += (int64_t)4 * H * y->I[l];
+            y->c_whh[ld] = c; c += (int64_t)4 * H * H;
+            y->c_bih[ld] = c; c += 4 * H;
+            y->c_bhh[ld] = c; c += 4 * H;
+            y->k_A[ld] = k; k += (int64_t)y->NW * y->KK[l] * 64;
+            y->k_bias[ld] = k; k += (int64_t)2 * y->NW * 32;
+        }
+    }
+    y->c_head_w = c; c += (int64_t)C * y->F;
+    y->c_head_b = c; c += C;
+    y->k_head_w = k; k += (int64_t)C * y->F;
+    y->k_head_b = k; k += C;
+    y->P = c;
+    y->PK = (k + 3) & ~(int64_t)3;  // keep weight sets 16-byte aligned
+    y->n_tensors = 4 * L * y->dirs + 1;
+    return 0;
+}

@@ -1,0 +1,258 @@
+"""Thin host layer over the C ABI: owns device buffers (torch tensors), builds the
+batching plan, and launches the kernels on torch's current HIP stream.
+
+PyTorch is plumbing here (allocator, streams); all arithmetic of the hot path
+runs in libsnn_hip.so.  Nothing in this module computes on the CPU.
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise L.SnnError(
+            f"{name} must live on a HIP device: supernnova_amd runs only on the GPU (no CPU fallback)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise L.SnnError(f"{name} must be contiguous float32")
+
+
+@dataclass(frozen=True)
+class Config:
+    """The settings the modules read (training/vanilla_rnn.py:9-16)."""
+    input_size: int
+    hidden_size: int
+    num_layers: int = 2
+    bidirectional: bool = True
+    nb_classes: int = 2
+    pool: str = "mean"
+
+    @property
+    def c(self):
+        return L.SnnCfg(self.input_size, self.hidden_size, self.num_layers, int(bool(self.bidirectional)),
+                        self.nb_classes, L.SNN_POOL_MEAN if self.pool == "mean" else L.SNN_POOL_STANDARD)
+
+    @property
+    def dirs(self):
+        return 2 if self.bidirectional else 1
+
+    @property
+    def P(self):
+        return L.check(L.load().snn_param_count(ctypes.byref(self.c)), "snn_param_count")
+
+    @property
+    def PK(self):
+        return L.check(L.load().snn_kparam_count(ctypes.byref(self.c)), "snn_kparam_count")
+
+    @property
+    def F(self):
+        return L.check(L.load().snn_feat(ctypes.byref(self.c)), "snn_feat")
+
+    @property
+    def n_tensors(self):
+        return 4 * self.num_layers * self.dirs + 1
+
+    def supported(self):
+        return bool(L.load().snn_supported(ctypes.byref(self.c)))
+
+
+class Plan:
+    """Length-sorted 32-curve tiling of a batch (snn_plan_build), host + device copies."""
+
+    def __init__(self, cfg, lengths, device=None):
+        lengths = np.ascontiguousarray(np.asarray(lengths), dtype=np.int32)
+        if lengths.ndim != 1 or lengths.size < 1:
+            raise L.SnnError("lengths must be a non-empty 1-D array")
+        self.cfg = cfg
+        self.n_curves = int(lengths.size)
+        self.n_tiles = (self.n_curves + L.TILE - 1) // L.TILE
+        npad = self.n_tiles * L.TILE
+        self.order = np.empty(npad, np.int32)
+        self.len_sorted = np.empty(npad, np.int32)
+        self.tile_T = np.empty(self.n_tiles, np.int32)
+        self.tile_off = np.empty(self.n_tiles + 1, np.int64)
+        i32 = ctypes.POINTER(ctypes.c_int32)
+        L.check(L.load().snn_plan_build(
+            ctypes.byref(cfg.c), lengths.ctypes.data_as(i32), self.n_curves,
+            self.order.ctypes.data_as(i32), self.len_sorted.ctypes.data_as(i32),
+            self.tile_T.ctypes.data_as(i32), self.tile_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))),
+            "snn_plan_build")
+        self.max_T = int(self.tile_T[0])
+        self.xp_floats = int(self.tile_off[-1])
+        self.lengths = lengths
+        self.device = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.d_order = torch.from_numpy(self.order).to(self.device)
+        self.d_len_sorted = torch.from_numpy(self.len_sorted).to(self.device)
+        self.d_tile_T = torch.from_numpy(self.tile_T).to(self.device)
+        self.d_tile_off = torch.from_numpy(self.tile_off).to(self.device)
+        return self
+
+
+def pack_x(cfg, plan, x, time_major=True):
+    """x: (T,B,D) (time_major) or (B,T,D) padded fp32 on the GPU -> packed tile buffer."""
+    _require_cuda(x, "x")
+    if x.dim() != 3 or x.size(-1) != cfg.input_size:
+        raise L.SnnError(f"x must be 3-D with last dim {cfg.input_size}, got {tuple(x.shape)}")
+    T, B = (x.size(0), x.size(1)) if time_major else (x.size(1), x.size(0))
+    if B != plan.n_curves or T < plan.max_T:
+        raise L.SnnError(f"x {tuple(x.shape)} does not match plan (n_curves={plan.n_curves}, max_T={plan.max_T})")
+    D = cfg.input_size
+    st, sn = (B * D, D) if time_major else (D, T * D)
+    xp = torch.empty(plan.xp_floats, dtype=torch.float32, device=x.device)
+    L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(x), st, sn, _ptr(plan.d_order), _ptr(plan.d_len_sorted),
+                                _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles, plan.xp_floats,
+                                _ptr(xp), _stream()), "snn_pack_x")
+    return xp
+
+
+def prepare_weights(cfg, flat):
+    """Canonical flat (P,) -> kernel layout (PK,)."""
+    _require_cuda(flat, "flat")
+    if flat.numel() != cfg.P:
+        raise L.SnnError(f"flat has {flat.numel()} floats, expected {cfg.P}")
+    wk = torch.empty(cfg.PK, dtype=torch.float32, device=flat.device)
+    L.check(L.load().snn_prepare_weights(ctypes.byref(cfg.c), _ptr(flat), _ptr(wk), _stream()), "snn_prepare_weights")
+    return wk
+
+
+@dataclass(frozen=True)
+class Prior:
+    """training/bayesian_rnn.py:753-763 for the LSTM and the output layer."""
+    pi: float = 0.75
+    log_sigma1: float = -1.0
+    log_sigma2: float = -7.0
+    log_sigma1_output: float = -1.0
+    log_sigma2_output: float = -7.0
+
+    @property
+    def c(self):
+        return L.SnnPrior(self.pi, math.exp(self.log_sigma1), math.exp(self.log_sigma2),
+                          math.exp(self.log_sigma1_output), math.exp(self.log_sigma2_output))
+
+
+def bbb_sample(cfg, mu, rho, n_samples, prior, eps=None, mean_field=False, seed=0, offset=0, want_kl=True):
+    """Draw n_samples weight sets. Returns (wk (S,PK), kl (S,) or None)."""
+    _require_cuda(mu, "mu")
+    _require_cuda(rho, "rho")
+    Ps = cfg.P - cfg.nb_classes
+    if mu.numel() != cfg.P or rho.numel() != Ps:
+        raise L.SnnError(f"mu/rho sizes {mu.numel()}/{rho.numel()} != {cfg.P}/{Ps}")
+    if mean_field:
+        mode = L.BBB_MFE
+    elif eps is not None:
+        _require_cuda(eps, "eps")
+        if eps.numel() != n_samples * Ps:
+            raise L.SnnError(f"eps has {eps.numel()} floats, expected {n_samples}x{Ps}")
+        mode = L.BBB_EPS
+    else:
+        mode = L.BBB_PHILOX
+    wk = torch.empty((n_samples, cfg.PK), dtype=torch.float32, device=mu.device)
+    kl = terms = None
+    if want_kl:
+        kl = torch.empty(n_samples, dtype=torch.float32, device=mu.device)
+        terms = torch.empty(n_samples * cfg.n_tensors, dtype=torch.float32, device=mu.device)
+    pr = prior.c
+    L.check(L.load().snn_bbb_sample(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset,
+                                    n_samples, ctypes.byref(pr), _ptr(wk), _ptr(kl), _ptr(terms), _stream()),
+            "snn_bbb_sample")
+    return wk, kl
+
+
+@dataclass
+class Masks:
+    """Variational dropout masks (host-drawn arrays) or a Philox request."""
+    mode: int = L.SNN_MASK_NONE
+    m_in: torch.Tensor = None    # (S,N,D)
+    m_whh: torch.Tensor = None   # (S,L,4H)
+    m_mid: torch.Tensor = None   # (S,L-1,mid_T,N,dirs*H)
+    m_out: torch.Tensor = None   # (S,N,F)
+    mid_T: int = 1
+    which: int = 0xF
+    dropout: float = 0.0
+    seed: int = 0
+    offset: int = 0
+
+    def c(self):
+        keep = 1.0 - self.dropout
+        scale = float(np.float32(1.0) / np.float32(keep)) if keep > 0 else 0.0
+        return L.SnnMasks(self.mode, self.which, self.mid_T, scale, keep, self.seed, self.offset,
+                          *(None if m is None else m.data_ptr() for m in (self.m_in, self.m_whh, self.m_mid, self.m_out)))
+
+
+_workspaces = {}
+
+
+def _workspace(cfg, max_T, device):
+    need = L.check(L.load().snn_lstm_forward_workspace_bytes(ctypes.byref(cfg.c), max_T),
+                   "snn_lstm_forward_workspace_bytes")
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def lstm_forward(cfg, plan, xp, wk, n_samples, masks=None, want_logits=True, want_probs=True,
+                 sample_major=True):
+    """Run the LSTM stack + head for n_samples draws of every curve.
+
+    wk: (PK,) shared by all samples or (S,PK) one set per sample.
+    Returns (logits, probs), each (S,N,C) if sample_major else (N,S,C), in ORIGINAL curve order.
+    """
+    _require_cuda(xp, "xp")
+    _require_cuda(wk, "wk")
+    dev = xp.device
+    N, C, S = plan.n_curves, cfg.nb_classes, n_samples
+    if wk.dim() == 1:
+        stride = 0
+        if wk.numel() != cfg.PK:
+            raise L.SnnError("shared wk must have PK floats")
+    else:
+        if wk.shape != (S, cfg.PK):
+            raise L.SnnError(f"wk shape {tuple(wk.shape)} != ({S},{cfg.PK})")
+        stride = cfg.PK
+    if xp.numel() != plan.xp_floats:
+        raise L.SnnError("xp does not match the plan")
+    shape = (S, N, C) if sample_major else (N, S, C)
+    os_s, os_n = (N * C, C) if sample_major else (C, S * C)
+    logits = torch.empty(shape, dtype=torch.float32, device=dev) if want_logits else None
+    probs = torch.empty(shape, dtype=torch.float32, device=dev) if want_probs else None
+    mc = None
+    if masks is not None and masks.mode != L.SNN_MASK_NONE:
+        if masks.mode == L.SNN_MASK_ARRAYS:
+            F, H, D, dirs, Ln = cfg.F, cfg.hidden_size, cfg.input_size, cfg.dirs, cfg.num_layers
+            exp = {"m_in": (S, N, D), "m_whh": (S, Ln, 4 * H),
+                   "m_mid": (S, Ln - 1, masks.mid_T, N, dirs * H), "m_out": (S, N, F)}
+            for k, shp in exp.items():
+                m = getattr(masks, k)
+                if m is not None:
+                    _require_cuda(m, k)
+                    if tuple(m.shape) != shp:
+                        raise L.SnnError(f"mask {k} shape {tuple(m.shape)} != {shp}")
+        mc = masks.c()
+    ws = _workspace(cfg, plan.max_T, dev)
+    L.check(L.load().snn_lstm_forward(
+        ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
+        _ptr(plan.d_tile_off), N, plan.n_tiles, plan.max_T, _ptr(wk), stride, S,
+        ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(probs), os_s, os_n,
+        _ptr(ws), ws.numel(), _stream()), "snn_lstm_forward")
+    return logits, probs
