@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- light curves/s classified, BayesianRNN, 50 MC samples (BASELINE.json metric).
+
+One "step" = one pass of the inference hot path over this rank's shard of
+synthetic light curves, all on the GPU with inputs already resident in HBM:
+  host plan (length sort + tiling)  -> snn_pack_x -> snn_bbb_sample (Philox, S
+  draws + KL) -> snn_lstm_forward (S x N forwards + head + softmax -> (N,S,C)).
+Inference shards curves across ranks with no collective on the data path
+(SURVEY 8e): scaling is weak (fixed curves per GPU); value = all ranks' curves /
+max-over-ranks time.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def synth_curves(n, T, F_filters, device, seed, redshift=False, chunk=250_000):
+    """SURVEY 8d generator: lengths ~ U{3..T}; per step one filter combination (one-hot over
+    2^F-1), normalised flux / flux-error ~ N(0,1) for the filters present and the normalised-zero
+    constant otherwise; delta_time ~ N(0,1) (first step = normalised 0). (T, n, D) time-major."""
+    D = 2 * F_filters + 1 + (2 ** F_filters - 1) + (2 if redshift else 0)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lengths = torch.randint(3, T + 1, (n,), generator=g, device=device, dtype=torch.int32)
+    x = torch.zeros((T, n, D), dtype=torch.float32, device=device)
+    FLUX0, ERR0, DT0 = -6.48, -1.31, -2.0  # log-standardised zeros (tests/onthefly_model/data_norm.json scales)
+    bits = torch.arange(F_filters, device=device)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        m = b - a
+        combo = torch.randint(1, 2 ** F_filters, (T, m), generator=g, device=device)
+        present = ((combo.unsqueeze(-1) >> bits) & 1).bool()
+        flux = torch.randn((T, m, F_filters), generator=g, device=device)
+        err = torch.randn((T, m, F_filters), generator=g, device=device)
+        xs = x[:, a:b]
+        xs[..., :F_filters] = torch.where(present, flux, torch.full_like(flux, FLUX0))
+        xs[..., F_filters:2 * F_filters] = torch.where(present, err, torch.full_like(err, ERR0))
+        dt = torch.randn((T, m), generator=g, device=device)
+        dt[0] = DT0
+        xs[..., 2 * F_filters] = dt
+        xs[..., 2 * F_filters + 1:2 * F_filters + 1 + 2 ** F_filters - 1].scatter_(
+            -1, (combo - 1).unsqueeze(-1), 1.0)
+        if redshift:
+            xs[..., -2] = torch.rand((1, m), generator=g, device=device) * 1.15 + 0.05
+            xs[..., -1] = torch.rand((1, m), generator=g, device=device) * 0.049 + 0.001
+        t = torch.arange(T, device=device).unsqueeze(-1)
+        xs.mul_((t < lengths[a:b].unsqueeze(0)).unsqueeze(-1))
+    return x, lengths
+
+
+def bayes_init(cfg, seed, device):
+    """Reference init (bayesian_rnn.py:55-62, 766-775): mu ~ U(-0.05, 0.05),
+    rho ~ U(log(exp(sigma_mix/4)-1), log(exp(sigma_mix/3)-1)), head bias 0."""
+    import math
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    pi, s1, s2 = 0.75, math.exp(-1.0), math.exp(-7.0)
+    mix = math.sqrt(pi * s1 * s1 + (1 - pi) * s2 * s2)
+    lo, hi = math.log(math.exp(mix / 4.0) - 1.0), math.log(math.exp(mix / 3.0) - 1.0)
+    P, C = cfg.P, cfg.nb_classes
+    mu = torch.rand(P, generator=g) * 0.1 - 0.05
+    mu[P - C:] = 0.0
+    rho = torch.rand(P - C, generator=g) * (hi - lo) + lo
+    return mu.to(device), rho.to(device)
+
+
+def flops_per_pass(cfg, lengths_sum, n_curves, S):
+    """per curve per sample l*16H(D+4H) + 4HC (L=2, bidirectional)."""
+    H, D, C = cfg.hidden_size, cfg.input_size, cfg.nb_classes
+    return S * (lengths_sum * 16 * H * (D + 4 * H) + n_curves * 4 * H * C)
+
+
+def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves):
+    """Reference call pattern (validate_rnn.py:539-563) on the stock-PyTorch CPU port."""
+    from oracle import torch_port as tp
+    from supernnova_amd import layout
+    sd, off = {}, 0
+    H, D, C, F = cfg.hidden_size, cfg.input_size, cfg.nb_classes, cfg.F
+    shapes = []
+    for l in range(cfg.num_layers):
+        I = D if l == 0 else 2 * H
+        shapes += [(4 * H, I), (4 * H, H), (4 * H,), (4 * H,)] * 2
+    shapes += [(C, F), (C,)]
+    mu_c, rho_c = mu.cpu(), rho.cpu()
+    for k_mu, k_rho, shp in zip(layout.bayesian_keys(2, 2, "mu"), layout.bayesian_keys(2, 2, "rho") + [None], shapes):
+        n = int(np.prod(shp))
+        sd[k_mu] = mu_c[off:off + n].view(shp).clone()
+        if k_rho is not None:
+            sd[k_rho] = rho_c[off:off + n].view(shp).clone()
+        off += n
+    curves = [x_host[:lengths_host[i], i].copy() for i in range(n_curves)]
+    t0 = time.perf_counter()
+    tp.mc_predict("bayesian", sd, curves, S, batch_size=128, hidden=H)
+    dt = time.perf_counter() - t0
+    return n_curves / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
+    ap.add_argument("--samples", type=int, default=50)
+    ap.add_argument("--max-len", type=int, default=40)
+    ap.add_argument("--cpu-curves", type=int, default=1280, help="curves of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from supernnova_amd import engine as E
+
+    cfg = E.Config(24, 32, 2, True, 2, "mean")
+    S, N = args.samples, args.curves
+    mu, rho = bayes_init(cfg, 0, dev)
+    x, lengths = synth_curves(N, args.max_len, 4, dev, seed=1000 + rank)
+    lengths_host = lengths.cpu().numpy()
+    prior = E.Prior()
+    torch.cuda.synchronize()
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    kern_ms = []
+
+    def step(i, timed):
+        plan = E.Plan(cfg, lengths_host, dev)
+        xp = E.pack_x(cfg, plan, x)
+        wk, kl = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i * S)
+        if timed:
+            ev[0].record()
+        _, probs = E.lstm_forward(cfg, plan, xp, wk, S, want_logits=False, want_probs=True, sample_major=False)
+        if timed:
+            ev[1].record()
+        return probs, kl
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        probs, kl = step(args.warmup + i, True)
+        ev[1].synchronize()
+        kern_ms.append(ev[0].elapsed_time(ev[1]))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(probs).all()) and bool(torch.isfinite(kl).all())
+
+    if rank == 0:
+        value = world * N * args.steps / dt
+        fl = flops_per_pass(cfg, int(lengths_host.astype(np.int64).sum()), N, S)
+        k_ms = float(np.mean(kern_ms))
+        achieved = fl / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "light curves/s classified, BayesianRNN 50 MC samples",
+            "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BayesianRNN (BBB) LSTM 32x2 bidirectional, mean pooling, D=24 (4 filters), "
+                                   f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
+                                   f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)",
+                       "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
+            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel<32,12,2>", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": k_ms, "flop_per_launch": fl},
+        }
+        if args.cpu_curves > 0 and world == 1:
+            n_cpu = min(args.cpu_curves, N)
+            v, secs = cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu)
+            out["cpu_baseline"] = {"value": v, "unit": "light curves/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": f"first {n_cpu} curves of the same workload, batches of 128 x {S} "
+                                             f"sequential forwards (reference call pattern), {secs:.1f} s"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

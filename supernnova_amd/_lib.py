@@ -77,6 +77,10 @@ def load():
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(`make -C supernnova_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "supernnova_amd has no CPU fallback.")
+        # The library shares device pointers and streams with PyTorch, so both must bind to the
+        # SAME HIP runtime: torch's wheel ships its own libamdhip64.so.7; loading torch first makes
+        # the dynamic loader resolve our NEEDED libamdhip64.so.7 to that already-loaded copy.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
