@@ -122,10 +122,14 @@ int snn_plan_build(const snn_cfg *cfg, const int32_t *lengths_host, int32_t n_cu
  *   xp[tile_off[i] + (t*Dp + k)*32 + c] = x[t, order[32i+c], k]   (0 beyond the curve / padding)
  * x is addressed as x[t*stride_t + n*stride_n + k]; (T,B,D) time-major has
  * stride_t = B*D, stride_n = D (the X_tensor of utils/training_utils.py:454-461).
+ * If curve_off != NULL the batch is RAGGED (no padding, the layout of the
+ * vlen rows in database.h5 and of list_data, utils/training_utils.py:127-191):
+ * curve n starts at float offset curve_off[n] and x[curve_off[n] + t*stride_t + k]
+ * is read (stride_t = D for concatenated (sum(len), D) rows; stride_n ignored).
  * order/len_sorted/tile_T/tile_off are DEVICE copies of the plan.
  */
 int snn_pack_x(const snn_cfg *cfg, const float *x, int64_t stride_t, int64_t stride_n,
-               const int32_t *order, const int32_t *len_sorted, const int32_t *tile_T,
+               const int64_t *curve_off, const int32_t *order, const int32_t *len_sorted, const int32_t *tile_T,
                const int64_t *tile_off, int32_t n_tiles, int64_t xp_floats, float *xp, void *stream);
 
 /*

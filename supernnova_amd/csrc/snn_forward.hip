@@ -21,6 +21,7 @@
 // ============================================================================
 __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float* __restrict__ x,
                                                     int64_t stride_t, int64_t stride_n,
+                                                    const int64_t* __restrict__ curve_off,
                                                     const int32_t* __restrict__ order,
                                                     const int32_t* __restrict__ len_sorted,
                                                     const int32_t* __restrict__ tile_T,
@@ -35,7 +36,8 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
         const int pos = tile * SNN_TILE + c;
         const int orig = order[pos];
         const bool live = orig >= 0 && t < len_sorted[pos];
-        const float* src = x + (int64_t)t * stride_t + (int64_t)(live ? orig : 0) * stride_n;
+        const int on = live ? orig : 0;
+        const float* src = x + (int64_t)t * stride_t + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
         float* o = dst + (int64_t)t * Dp * SNN_TILE + c;
         for (int k = 0; k < Dp; ++k) o[(int64_t)k * SNN_TILE] = (live && k < D) ? src[k] : 0.0f;
     }
@@ -658,7 +660,7 @@ extern "C" int snn_plan_build(const snn_cfg* cfg, const int32_t* lengths, int32_
     } while (0)
 
 extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, int64_t stride_n,
-                          const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
+                          const int64_t* curve_off, const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
                           const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp, void* stream)
 {
     SnnLayout y;
@@ -670,7 +672,7 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
     }
     (void)xp_floats;
     hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
-                       stride_n, order, len_sorted, tile_T, tile_off, xp);
+                       stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }

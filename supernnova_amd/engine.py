@@ -117,9 +117,27 @@ def pack_x(cfg, plan, x, time_major=True):
     D = cfg.input_size
     st, sn = (B * D, D) if time_major else (D, T * D)
     xp = torch.empty(plan.xp_floats, dtype=torch.float32, device=x.device)
-    L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(x), st, sn, _ptr(plan.d_order), _ptr(plan.d_len_sorted),
-                                _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles, plan.xp_floats,
-                                _ptr(xp), _stream()), "snn_pack_x")
+    L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(x), st, sn, None, _ptr(plan.d_order),
+                                _ptr(plan.d_len_sorted), _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles,
+                                plan.xp_floats, _ptr(xp), _stream()), "snn_pack_x")
+    return xp
+
+
+def pack_ragged(cfg, plan, rows, curve_off):
+    """rows: concatenated (sum(len), D) fp32 on the GPU; curve_off: int64 (N,) float offset of each
+    curve's first row (device).  No padded copy is ever materialised."""
+    _require_cuda(rows, "rows")
+    D = cfg.input_size
+    if rows.dim() != 2 or rows.size(1) != D:
+        raise L.SnnError(f"rows must be (sum(len), {D}), got {tuple(rows.shape)}")
+    if curve_off.dtype != torch.int64 or curve_off.numel() != plan.n_curves or not curve_off.is_cuda:
+        raise L.SnnError("curve_off must be a device int64 tensor with one entry per curve")
+    if rows.size(0) != int(plan.lengths.astype(np.int64).sum()):
+        raise L.SnnError("rows does not hold sum(lengths) rows")
+    xp = torch.empty(plan.xp_floats, dtype=torch.float32, device=rows.device)
+    L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(rows), D, 0, _ptr(curve_off), _ptr(plan.d_order),
+                                _ptr(plan.d_len_sorted), _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles,
+                                plan.xp_floats, _ptr(xp), _stream()), "snn_pack_x")
     return xp
 
 

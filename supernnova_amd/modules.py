@@ -1,0 +1,364 @@
+"""nn.Module mirror of the reference's three RNN classes over the HIP kernels.
+
+Same constructor (`cls(input_size, settings)`), same `forward(x,
+mean_field_inference=False)` contract (x a PackedSequence or a dense (T,B,D)
+tensor, returns logits (B,C)), same state_dict key names/shapes and the same
+parameter initialisation (same torch RNG calls in the same order), so reference
+checkpoints load and a seeded construction gives identical weights:
+  VanillaRNN      training/vanilla_rnn.py:4-90
+  VariationalRNN  training/variational_rnn.py:4-244
+  BayesianRNN     training/bayesian_rnn.py:21-139, 146-270, 574-616, 753-775
+The modules hold parameters only; every FLOP of forward runs in libsnn_hip.so.
+CPU tensors are rejected (no fallback).
+
+Random draws.  `draws = "philox"` (default): masks / eps come from the in-kernel
+Philox4x32-10 stream keyed by a seed taken from torch's CPU generator at each
+forward (so torch.manual_seed makes runs reproducible).  `draws = "host"` (parity
+mode): the draws are made on the host with exactly the reference's torch calls in
+the reference's order and shipped to the kernels, so a run seeded like
+a reference CPU run reproduces its outputs to fp32 rounding.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn.utils.rnn import PackedSequence, pad_packed_sequence
+
+from . import _lib as L
+from . import engine as E
+
+
+def _dirs(bidirectional):
+    return 2 if bidirectional else 1
+
+
+class _LSTMParams(nn.Module):
+    """Parameter container with torch.nn.LSTM's names, shapes, registration order and
+    reset_parameters() (U(-1/sqrt(H), 1/sqrt(H)) over parameters in order)."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        dirs = _dirs(bidirectional)
+        G = 4 * hidden_size
+        for l in range(num_layers):
+            I = input_size if l == 0 else hidden_size * dirs
+            for d in range(dirs):
+                s = "_reverse" if d else ""
+                for name, shape in ((f"weight_ih_l{l}{s}", (G, I)), (f"weight_hh_l{l}{s}", (G, hidden_size)),
+                                    (f"bias_ih_l{l}{s}", (G,)), (f"bias_hh_l{l}{s}", (G,))):
+                    self.register_parameter(name, nn.Parameter(torch.empty(shape)))
+        stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+
+class _WeightDropParams(nn.Module):
+    """`rnn_layer{i}` of VariationalRNN: holds `.module` whose weight_hh_l0 was re-registered
+    as weight_hh_l0_raw (variational_rnn.py:216-222), keeping the reference's key order."""
+
+    def __init__(self, input_size, hidden_size, bidirectional):
+        super().__init__()
+        m = _LSTMParams(input_size, hidden_size, 1, bidirectional)
+        w = m._parameters.pop("weight_hh_l0")
+        m.register_parameter("weight_hh_l0_raw", nn.Parameter(w.data))
+        self.module = m
+
+
+def _check_settings(settings):
+    if settings.layer_type != "lstm":
+        raise ValueError(f"supernnova_amd implements layer_type 'lstm' only, got {settings.layer_type!r}")
+    if settings.rnn_output_option not in ("mean", "standard"):
+        raise ValueError(f"unknown rnn_output_option {settings.rnn_output_option!r}")
+
+
+class _HipRNN(nn.Module):
+    """Shared host logic: input unpacking, plan/pack, launch."""
+
+    draws = "philox"
+
+    def _init_common(self, input_size, settings):
+        _check_settings(settings)
+        self.input_size = input_size
+        self.layer_type = settings.layer_type
+        self.output_size = settings.nb_classes
+        self.hidden_size = settings.hidden_dim
+        self.num_layers = settings.num_layers
+        self.bidirectional = bool(settings.bidirectional)
+        self.use_cuda = settings.use_cuda
+        self.rnn_output_option = settings.rnn_output_option
+        self.cfg = E.Config(input_size, self.hidden_size, self.num_layers, self.bidirectional,
+                            self.output_size, self.rnn_output_option)
+        self._flat_cache = {}
+
+    @property
+    def last_input_size(self):
+        f = self.hidden_size * _dirs(self.bidirectional)
+        return f if self.rnn_output_option == "mean" else f * self.num_layers
+
+    # -- parameters -> canonical flat buffer (cached on parameter versions)
+    def _flat(self, keys, tag):
+        params = dict(self.named_parameters())
+        ps = [params[k] for k in keys]
+        sig = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self._flat_cache.get(tag)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, torch.cat([p.detach().reshape(-1) for p in ps]).float().contiguous())
+            self._flat_cache[tag] = hit
+        return hit[1]
+
+    # -- x -> (padded (T,B,D) on device, host lengths)
+    def _unpack(self, x):
+        if isinstance(x, PackedSequence):
+            if x.data.dim() != 2:
+                raise RuntimeError(f"input must have 2 dimensions, got {x.data.dim()}")
+            if x.data.size(-1) != self.input_size:
+                raise RuntimeError("input.size(-1) must be equal to input_size. Expected {}, got {}".format(
+                    self.input_size, x.data.size(-1)))
+            padded, lens = pad_packed_sequence(x)
+            lengths = lens.numpy().astype(np.int32)
+        else:
+            if x.dim() != 3:
+                raise RuntimeError(f"input must have 3 dimensions, got {x.dim()}")
+            if x.size(-1) != self.input_size:
+                raise RuntimeError("input.size(-1) must be equal to input_size. Expected {}, got {}".format(
+                    self.input_size, x.size(-1)))
+            padded = x
+            lengths = np.full(x.size(1), x.size(0), np.int32)  # dense input runs over padding (vanilla_rnn.py:82-83)
+        if not padded.is_cuda:
+            raise L.SnnError("supernnova_amd modules run on the GPU only: move the module and its input "
+                             "to a HIP device (there is no CPU fallback)")
+        return padded.float().contiguous(), lengths
+
+    def _seed(self):
+        return int(torch.empty((), dtype=torch.int64).random_().item())
+
+    def _launch(self, x, wk, n_samples, masks=None, want_probs=False):
+        padded, lengths = self._unpack(x)
+        if not self.cfg.supported():
+            raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
+        plan = E.Plan(self.cfg, lengths, padded.device)
+        xp = E.pack_x(self.cfg, plan, padded)
+        return E.lstm_forward(self.cfg, plan, xp, wk, n_samples, masks=masks, want_logits=True,
+                              want_probs=want_probs, sample_major=True), plan
+
+
+class VanillaRNN(_HipRNN):
+    def __init__(self, input_size, settings):
+        super().__init__()
+        self._init_common(input_size, settings)
+        self.dropout = settings.dropout
+        self.rnn_layer = _LSTMParams(input_size, self.hidden_size, self.num_layers, self.bidirectional)
+        self.output_dropout_layer = nn.Dropout(self.dropout)
+        self.output_layer = nn.Linear(self.last_input_size, self.output_size)
+
+    def _keys(self):
+        from .layout import vanilla_keys
+        return vanilla_keys(self.num_layers, _dirs(self.bidirectional))
+
+    def _masks(self, n_curves, lengths_max, device):
+        """train mode only: torch.nn.LSTM's inter-layer dropout + nn.Dropout on the pooled features."""
+        if not self.training or self.dropout <= 0:
+            return None
+        if self.draws == "host":
+            raise L.SnnError("VanillaRNN train-mode host draws are supplied through forward_train()")
+        which = (4 if self.num_layers > 1 else 0) | 8
+        return E.Masks(mode=L.SNN_MASK_PHILOX, which=which, dropout=self.dropout, seed=self._seed())
+
+    def forward(self, x, mean_field_inference=False):
+        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        masks = self._masks(None, None, None)
+        (logits, _), _ = self._launch(x, wk, 1, masks)
+        return logits[0]
+
+    def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
+        """(kernel-layout weights, masks) for n_samples forwards over n_curves curves."""
+        return E.prepare_weights(self.cfg, self._flat(self._keys(), "w")), self._masks(None, None, None)
+
+    def forward_mc(self, x, n_samples=1, mean_field_inference=False):
+        """probs (B, n_samples, C); a vanilla model is deterministic in eval mode."""
+        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        (_, probs), _ = self._launch(x, wk, n_samples, self._masks(None, None, None), want_probs=True)
+        return probs.permute(1, 0, 2)
+
+
+class VariationalRNN(_HipRNN):
+    def __init__(self, input_size, settings):
+        super().__init__()
+        self._init_common(input_size, settings)
+        self.dropout = settings.dropout
+        dirs = _dirs(self.bidirectional)
+        for i in range(self.num_layers):
+            I = input_size if i == 0 else self.hidden_size * dirs
+            setattr(self, f"rnn_layer{i}", _WeightDropParams(I, self.hidden_size, self.bidirectional))
+        self.output_layer = nn.Linear(self.last_input_size, self.output_size)
+
+    def _keys(self):
+        from .layout import variational_keys
+        return variational_keys(self.num_layers, _dirs(self.bidirectional))
+
+    def host_masks(self, n_samples, n_curves, device):
+        """Draw the masks on the host with the reference's calls in the reference's order
+        (input (1,B,D) -> per layer [W_hh rows (4H,1) -> locked (1,B,2H)] -> output (B,F))."""
+        p, H, Ln, D = self.dropout, self.hidden_size, self.num_layers, self.input_size
+        dH, F = _dirs(self.bidirectional) * H, self.last_input_size
+
+        def bern(*shape):
+            return torch.empty(shape).bernoulli_(1 - p).div_(1 - p)
+
+        m_in, m_whh, m_mid, m_out = [], [], [], []
+        for _ in range(n_samples):
+            m_in.append(bern(1, n_curves, D)[0])
+            whh, mid = [], []
+            for l in range(Ln):
+                whh.append(bern(4 * H, 1)[:, 0])
+                if l != Ln - 1:
+                    mid.append(bern(1, n_curves, dH))
+            m_whh.append(torch.stack(whh))
+            m_mid.append(torch.stack(mid) if mid else torch.empty(0, 1, n_curves, dH))
+            m_out.append(bern(n_curves, F))
+        to = lambda ts: torch.stack(ts).to(device).contiguous()
+        return E.Masks(mode=L.SNN_MASK_ARRAYS, m_in=to(m_in), m_whh=to(m_whh),
+                       m_mid=to(m_mid) if Ln > 1 else None, m_out=to(m_out), mid_T=1)
+
+    def _masks(self, n_samples, n_curves, device, mean_field_inference):
+        if mean_field_inference or self.dropout <= 0:
+            return None
+        if self.draws == "host":
+            return self.host_masks(n_samples, n_curves, device)
+        return E.Masks(mode=L.SNN_MASK_PHILOX, which=0xF, dropout=self.dropout, seed=self._seed())
+
+    def _n_curves(self, x):
+        return int(x.batch_sizes[0]) if isinstance(x, PackedSequence) else x.size(1)
+
+    def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
+        """(kernel-layout weights, masks) for n_samples MC-dropout forwards over n_curves curves."""
+        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        return wk, self._masks(n_samples, n_curves, device, mean_field_inference)
+
+    def forward(self, x, mean_field_inference=False, masks=None):
+        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        dev = x.data.device if isinstance(x, PackedSequence) else x.device
+        if masks is None:
+            masks = self._masks(1, self._n_curves(x), dev, mean_field_inference)
+        (logits, _), _ = self._launch(x, wk, 1, masks)
+        return logits[0]
+
+    def forward_mc(self, x, n_samples, mean_field_inference=False, masks=None):
+        """All n_samples MC-dropout forwards in one launch -> probs (B, n_samples, C)."""
+        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        dev = x.data.device if isinstance(x, PackedSequence) else x.device
+        if masks is None:
+            masks = self._masks(n_samples, self._n_curves(x), dev, mean_field_inference)
+        (_, probs), _ = self._launch(x, wk, n_samples, masks, want_probs=True)
+        return probs.permute(1, 0, 2)
+
+
+class Prior(object):
+    """training/bayesian_rnn.py:753-763."""
+
+    def __init__(self, pi=0.25, log_sigma1=-1.0, log_sigma2=-7.0):
+        self.pi_mixture = pi
+        self.log_sigma1, self.log_sigma2 = log_sigma1, log_sigma2
+        self.sigma1, self.sigma2 = math.exp(log_sigma1), math.exp(log_sigma2)
+        self.sigma_mix = math.sqrt(pi * self.sigma1 ** 2 + (1.0 - pi) * self.sigma2 ** 2)
+
+
+def _bbb_pair(shape, mu_lower, mu_upper, rho_lower, rho_upper):
+    """get_bbb_variable (bayesian_rnn.py:766-775): mu then rho, uniform."""
+    mu, rho = nn.Parameter(torch.empty(*shape)), nn.Parameter(torch.empty(*shape))
+    mu.data.uniform_(mu_lower, mu_upper)
+    rho.data.uniform_(rho_lower, rho_upper)
+    return mu, rho
+
+
+class _BayesLSTMParams(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional, rho_lower, rho_upper):
+        super().__init__()
+        dirs = _dirs(bidirectional)
+        G = 4 * hidden_size
+        for l in range(num_layers):
+            for d in range(dirs):
+                I = input_size if l == 0 else hidden_size * dirs
+                s = "_reverse" if d else ""
+                pairs = [_bbb_pair(shp, -0.05, 0.05, rho_lower, rho_upper)
+                         for shp in ((G, I), (G, hidden_size), (G,), (G,))]
+                for n, (mu, rho) in zip(("weight_ih", "weight_hh", "bias_ih", "bias_hh"), pairs):
+                    self.register_parameter(f"{n}_mu_l{l}{s}", mu)
+                    self.register_parameter(f"{n}_rho_l{l}{s}", rho)
+
+
+class _BayesLinearParams(nn.Module):
+    def __init__(self, in_features, out_features, rho_lower, rho_upper):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.mu, self.rho = _bbb_pair((out_features, in_features), -0.05, 0.05, rho_lower, rho_upper)
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+
+class BayesianRNN(_HipRNN):
+    def __init__(self, input_size, settings):
+        super().__init__()
+        self._init_common(input_size, settings)
+        self.prior = Prior(settings.pi, settings.log_sigma1, settings.log_sigma2)
+        self.prior_output = Prior(settings.pi, settings.log_sigma1_output, settings.log_sigma2_output)
+        rl = lambda prior, scale: math.log(math.exp(prior.sigma_mix / scale) - 1.0)
+        self.rnn_layer = _BayesLSTMParams(input_size, self.hidden_size, self.num_layers, self.bidirectional,
+                                          rl(self.prior, settings.rho_scale_lower),
+                                          rl(self.prior, settings.rho_scale_upper))
+        self.output_layer = _BayesLinearParams(self.last_input_size, self.output_size,
+                                               rl(self.prior_output, settings.rho_scale_lower_output),
+                                               rl(self.prior_output, settings.rho_scale_upper_output))
+        self._prior = E.Prior(settings.pi, settings.log_sigma1, settings.log_sigma2,
+                              settings.log_sigma1_output, settings.log_sigma2_output)
+        self.kl = None
+        self._draw_count = 0
+
+    def _mu_rho(self):
+        from .layout import bayesian_keys
+        dirs = _dirs(self.bidirectional)
+        return (self._flat(bayesian_keys(self.num_layers, dirs, "mu"), "mu"),
+                self._flat(bayesian_keys(self.num_layers, dirs, "rho"), "rho"))
+
+    def host_eps(self, n_samples, device):
+        """eps drawn like the reference (bayesian_rnn.py:492-523, 608): one CPU normal_ per tensor,
+        in the order w_ih, w_hh, b_ih, b_hh per (layer, direction), then the head."""
+        from .layout import bayesian_keys
+        params = dict(self.named_parameters())
+        keys = bayesian_keys(self.num_layers, _dirs(self.bidirectional), "rho")
+        rows = [torch.cat([torch.empty(params[k].shape).normal_(0.0, 1.0).reshape(-1) for k in keys])
+                for _ in range(n_samples)]
+        return torch.stack(rows).to(device).contiguous()
+
+    def _sample(self, n_samples, mean_field_inference, eps, device):
+        mu, rho = self._mu_rho()
+        if not mean_field_inference and eps is None and self.draws == "host":
+            eps = self.host_eps(n_samples, device)
+        seed = offset = 0
+        if not mean_field_inference and eps is None:
+            seed = self._seed()
+        return E.bbb_sample(self.cfg, mu, rho, n_samples, self._prior, eps=eps,
+                            mean_field=mean_field_inference, seed=seed, offset=offset)
+
+    def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False, eps=None):
+        """(n_samples weight draws in kernel layout, None); sets self.kl to the (S,) KL vector."""
+        wk, self.kl = self._sample(n_samples, mean_field_inference, eps, device)
+        return wk, None
+
+    def forward(self, x, mean_field_inference=False, eps=None):
+        dev = x.data.device if isinstance(x, PackedSequence) else x.device
+        wk, kl = self._sample(1, mean_field_inference, eps, dev)
+        (logits, _), _ = self._launch(x, wk, 1)
+        self.kl = kl[0]
+        return logits[0]
+
+    def forward_mc(self, x, n_samples, mean_field_inference=False, eps=None):
+        """n_samples weight draws x all curves in one launch -> probs (B, n_samples, C); self.kl (S,)."""
+        dev = x.data.device if isinstance(x, PackedSequence) else x.device
+        wk, kl = self._sample(n_samples, mean_field_inference, eps, dev)
+        (_, probs), _ = self._launch(x, wk, n_samples, want_probs=True)
+        self.kl = kl
+        return probs.permute(1, 0, 2)

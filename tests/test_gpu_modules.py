@@ -1,0 +1,135 @@
+"""GPU: the module API (drop-in boundary) against the reference's golden vectors.
+
+With `draws = "host"` the modules draw eps / masks on the host with the reference's torch calls
+in the reference's order, so seeding exactly like the reference run that produced the fixture
+(tools/make_golden.py) must reproduce its logits to fp32 rounding -- the parity mode of
+BASELINE.json's north_star (probabilities within 1e-5 relative)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from torch.nn.utils.rnn import pack_padded_sequence
+
+import oracle
+from supernnova_amd import layout
+from util import load_golden, flat, rel_err, softmax_np, make_curves, PROB_RTOL, LOGIT_ATOL
+from test_host_logic import settings
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(name, sd, D, **kw):
+    from supernnova_amd.utils import training_utils as tu
+    rnn = tu.get_model(settings(model=name, **kw), D)
+    rnn.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return rnn.to(DEV).eval()
+
+
+def _packed(g, xk="x", lk="lengths"):
+    return pack_padded_sequence(torch.from_numpy(g[xk]).to(DEV), torch.from_numpy(g[lk].astype(np.int64)))
+
+
+def _close(logits, ref):
+    logits = logits.detach().cpu().numpy()
+    np.testing.assert_allclose(logits, ref, atol=LOGIT_ATOL, rtol=0)
+    assert rel_err(softmax_np(logits), softmax_np(ref)) < PROB_RTOL
+
+
+def test_vanilla_module():
+    from supernnova_amd.validation import validate_rnn as vr
+    g = load_golden("g1_vanilla_mean")
+    rnn = _model("vanilla", g["sd"], 24)
+    with torch.no_grad():
+        _close(rnn(_packed(g)), g["logits"])
+        _close(rnn(torch.from_numpy(g["x"]).to(DEV)), g["logits_dense"])
+        _close(rnn(_packed(g, "x_b1", "lengths_b1")), g["logits_b1"])
+        preds, tgt = vr.get_batch_predictions(rnn, _packed(g), torch.zeros(16, dtype=torch.long, device=DEV))
+    assert preds.dtype == np.float32 and rel_err(preds, g["probs"]) < PROB_RTOL
+
+
+@pytest.mark.parametrize("tag,kw,D", [("mean", {}, 24), ("standard", dict(rnn_output_option="standard", nb_classes=4), 26)])
+def test_variational_module_seed_replay(tag, kw, D):
+    g = load_golden(f"g2_variational_{tag}")
+    rnn = _model("variational", g["sd"], D, **kw)
+    rnn.draws = "host"
+    with torch.no_grad():
+        for s in range(g["logits"].shape[0]):
+            torch.manual_seed(1000 + s)
+            _close(rnn(_packed(g)), g["logits"][s])
+        _close(rnn(_packed(g), mean_field_inference=True), g["logits_mfe"])
+        torch.manual_seed(77)
+        _close(rnn(torch.from_numpy(g["x"]).to(DEV)), g["logits_dense"])
+
+
+@pytest.mark.parametrize("tag,kw,D", [("mean", {}, 24), ("standard", dict(rnn_output_option="standard", nb_classes=3), 26),
+                                      ("h64", dict(hidden_dim=64, nb_classes=5), 24)])
+def test_bayesian_module_seed_replay(tag, kw, D):
+    g = load_golden(f"g3_bayesian_{tag}")
+    rnn = _model("bayesian", g["sd"], D, **kw)
+    rnn.draws = "host"
+    with torch.no_grad():
+        for s in range(g["logits"].shape[0]):
+            torch.manual_seed(2000 + s)
+            _close(rnn(_packed(g)), g["logits"][s])
+            assert abs(float(rnn.kl) - g["kl"][s]) / g["kl"][s] < 1e-5
+        _close(rnn(_packed(g), mean_field_inference=True), g["logits_mfe"])
+        assert abs(float(rnn.kl) - g["kl_mfe"]) / g["kl_mfe"] < 1e-5
+        torch.manual_seed(2100)
+        _close(rnn(torch.from_numpy(g["x"]).to(DEV)), g["logits_dense"])
+
+
+def test_forward_mc_and_ragged_predict_match_sequential_forwards():
+    """forward_mc / predict_mc (one launch, MC folded into the batch) == S sequential forwards."""
+    from supernnova_amd.validation import validate_rnn as vr
+    g = load_golden("g3_bayesian_mean")
+    rnn = _model("bayesian", g["sd"], 24)
+    S = 5
+    eps = rnn.host_eps(S, DEV)
+    with torch.no_grad():
+        mc = rnn.forward_mc(_packed(g), S, eps=eps).cpu().numpy()            # (B,S,C)
+        kl_mc = rnn.kl.cpu().numpy()
+        for s in range(S):
+            lo = rnn(_packed(g), eps=eps[s:s + 1])
+            assert rel_err(mc[:, s], softmax_np(lo.cpu().numpy())) < PROB_RTOL
+            assert abs(float(rnn.kl) - kl_mc[s]) == 0.0
+        # ragged list-of-curves entry point, unsorted order
+        perm = np.random.default_rng(0).permutation(g["x"].shape[1])
+        curves = [g["x"][: g["lengths"][b], b] for b in perm]
+        wk, _ = rnn.mc_weights(S, len(curves), DEV, eps=eps)
+        from supernnova_amd import engine as E
+        rows, off, lens = vr.ragged_to_device(curves, DEV)
+        plan = E.Plan(rnn.cfg, lens, DEV)
+        _, pr = E.lstm_forward(rnn.cfg, plan, E.pack_ragged(rnn.cfg, plan, rows, off), wk, S, sample_major=False)
+    assert np.array_equal(pr.cpu().numpy(), mc[perm])
+
+
+@pytest.mark.parametrize("model", ["bayesian", "variational"])
+def test_sampled_mode_statistics(model):
+    """Sampled (Philox) mode vs the reference's predictive mean/std (2000 reference draws, fixture g5).
+    Tolerances: per-curve |mean - mean_ref| <= 4*sqrt(2)*std_ref/sqrt(S) for >= 99.9 % of curves
+    (+1e-4 absolute floor), pooled mean bias < 1e-3, pooled predictive std within +-10 %."""
+    from supernnova_amd.validation import validate_rnn as vr
+    g = load_golden(f"g5_mcstats_{model}")
+    rnn = _model(model, g["sd"], 24, dropout=float(g["dropout"]))
+    S = 2000
+    torch.manual_seed(123)
+    curves = [g["x"][: g["lengths"][b], b] for b in range(g["x"].shape[1])]
+    with torch.no_grad():
+        probs = vr.predict_mc(rnn, curves, S).cpu().numpy().astype(np.float64)   # (N,S,C)
+    mean, std = probs.mean(1), probs.std(1, ddof=1)
+    ref_m, ref_s = g["mean"], g["std"]
+    n_ref = int(g["n_ref"])
+    bound = 4 * np.sqrt(2) * ref_s / np.sqrt(min(S, n_ref)) + 1e-4
+    ok = (np.abs(mean - ref_m) <= bound).mean()
+    assert ok >= 0.999, ok
+    assert abs((mean - ref_m).mean()) < 1e-3
+    ratio = std[:, 1].mean() / ref_s[:, 1].mean()
+    assert 0.9 < ratio < 1.1, ratio
+    # two different seeds give different draws; the same seed reproduces bit-for-bit
+    with torch.no_grad():
+        torch.manual_seed(5); a = vr.predict_mc(rnn, curves, 4).cpu().numpy()
+        torch.manual_seed(5); b = vr.predict_mc(rnn, curves, 4).cpu().numpy()
+        torch.manual_seed(6); c = vr.predict_mc(rnn, curves, 4).cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)

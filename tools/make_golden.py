@@ -145,6 +145,19 @@ def bern(shape, p):
     return torch.empty(shape).bernoulli_(1 - p).div_(1 - p).numpy().copy()
 
 
+# ---------------------------------------------------------------- G0 init
+def g0_init():
+    """state_dicts right after a seeded construction: the modules of supernnova_amd must
+    reproduce names, shapes, order AND values (same torch RNG calls in the same order)."""
+    for model, cls in (("vanilla", vanilla_rnn.VanillaRNN), ("variational", variational_rnn.VariationalRNN),
+                       ("bayesian", bayesian_rnn.BayesianRNN)):
+        for tag, kw, D in (("mean", {}, 24), ("standard", dict(rnn_output_option="standard", nb_classes=3), 26)):
+            torch.manual_seed(7)
+            m = build(cls, D, settings(**kw))
+            sd = sd_np(m)
+            save(f"g0_init_{model}_{tag}", sd=sd, keys=np.array(list(sd.keys())))
+
+
 # ---------------------------------------------------------------- G1 vanilla
 def g1_vanilla():
     st = settings()
@@ -460,7 +473,9 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5"]
+    if "g0" in which:
+        g0_init()
     if "g1" in which:
         g1_vanilla()
     if "g2" in which:
