@@ -79,16 +79,19 @@ typedef struct snn_prior {
  *                             torch.nn.LSTM(dropout=p) in train mode (vanilla_rnn.py:26-32)
  *   out  (S, N, F)            output dropout             :138-140, 182-188
  * Any pointer may be NULL (= no such mask).  In PHILOX mode the pointers are
- * ignored and `which` selects the masks to draw (bit 0 in, 1 whh, 2 mid, 3 out).
+ * ignored, `which` selects the masks to draw (bit 0 in, 1 whh, 2 mid, 3 out) and
+ * mid_T > 1 asks for a per-step between-layer mask.
  */
 typedef struct snn_masks {
     int32_t mode;  /* SNN_MASK_* */
     int32_t which; /* PHILOX mode: bitmask of masks to draw */
-    int32_t mid_T; /* ARRAYS mode: 1 or max_T */
+    int32_t mid_T; /* 1 (locked) or max_T (per step) */
     float keep_scale; /* PHILOX mode: 1/(1-p) as fp32 */
     float keep_prob;  /* PHILOX mode: 1-p */
     uint64_t seed;    /* PHILOX mode */
     uint64_t offset;  /* PHILOX mode: draw counter of sample 0 (sample s uses offset+s) */
+    uint32_t curve_base; /* PHILOX mode: global index of local curve 0 (data-parallel ranks draw distinct per-curve masks) */
+    uint32_t reserved;
     const float *in, *whh, *mid, *out;
 } snn_masks;
 
@@ -151,7 +154,8 @@ int snn_prepare_weights(const snn_cfg *cfg, const float *flat, float *wk, void *
  *   mode: 0 = use eps; 1 = mean_field_inference (w = mu, :486-488); 2 = Philox N(0,1)
  *         keyed by (seed, offset + s, parameter index)
  *   wk  (S, PK)  out: kernel-layout weights;  kl (S) out, may be NULL
- *   kl_terms     scratch of S*(4*L*dirs+1) floats (caller-owned), may be NULL iff kl is NULL
+ *   kl_terms     S*(4*L*dirs+1)*3 floats (caller-owned), may be NULL iff kl is NULL: per sample and
+ *                tensor (KL term, r1, r2) with r_k the mixture responsibilities snn_bbb_backward needs
  */
 int snn_bbb_sample(const snn_cfg *cfg, const float *mu, const float *rho, const float *eps,
                    int32_t mode, uint64_t seed, uint64_t offset, int32_t n_samples,
@@ -180,6 +184,71 @@ int snn_lstm_forward(const snn_cfg *cfg, const float *xp, const int32_t *len_sor
                      float *out_logits, float *out_probs, int64_t out_stride_sample,
                      int64_t out_stride_curve, void *workspace, int64_t workspace_bytes,
                      void *stream);
+
+/* ---- training ------------------------------------------------------------- */
+
+/* Floats of the activation tape snn_lstm_forward_train writes for n_tiles tiles. */
+int64_t snn_train_tape_floats(const snn_cfg *cfg, int32_t n_tiles, int32_t max_T);
+
+/*
+ * Training forward of ONE weight set (the reference draws one set per mini-batch,
+ * bayesian_rnn.py:492-496): as snn_lstm_forward with n_samples = 1, and additionally records
+ * gates, cell and hidden states of every step plus the pooled features on `tape` for the
+ * backward.  Replaces `output = rnn(packed_tensor)` in utils/training_utils.py:514.
+ * out_logits (N, C) in original curve order.
+ */
+int snn_lstm_forward_train(const snn_cfg *cfg, const float *xp, const int32_t *len_sorted,
+                           const int32_t *order, const int32_t *tile_T, const int64_t *tile_off,
+                           int32_t n_curves, int32_t n_tiles, int32_t max_T, const float *wk,
+                           const snn_masks *masks, float *out_logits, float *tape, int64_t tape_floats,
+                           void *workspace, int64_t workspace_bytes, void *stream);
+
+int64_t snn_lstm_backward_workspace_bytes(const snn_cfg *cfg, int32_t n_tiles, int32_t max_T);
+
+/*
+ * BPTT: gradients of a scalar loss w.r.t. the weight set used by snn_lstm_forward_train, given
+ * dlogits = dloss/dlogits (N, C) in original curve order; replaces autograd's traversal of
+ * aten::lstm + pooling + output layer in `loss.backward()` (utils/training_utils.py:523).
+ * dflat (P) receives (accumulate = 0) or accumulates (1) the gradient in canonical flat order;
+ * for VariationalRNN the W_hh gradient is that of weight_hh_l0_raw (variational_rnn.py:237).
+ * masks must be the ones of the forward.  Deterministic (fixed summation order).
+ */
+int snn_lstm_backward(const snn_cfg *cfg, const float *xp, const int32_t *len_sorted, const int32_t *order,
+                      const int32_t *tile_T, const int64_t *tile_off, int32_t n_curves, int32_t n_tiles,
+                      int32_t max_T, const float *wk, const snn_masks *masks, const float *tape,
+                      int64_t tape_floats, const float *dlogits, float *dflat, int32_t accumulate,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * Bayes-by-Backprop backward for one draw: from dw = dCE/dw (P, canonical; head bias at the tail)
+ * to dmu (P) and drho (P - C) of  loss = CE + kl_scale * KL  (utils/training_utils.py:517-518 with
+ * kl_scale = 1/(num_batches*batch_size)); autograd of bayesian_rnn.py:472-528, 595-616, 794-815.
+ * eps/mode/seed/offset and kl_terms must be those of the forward's snn_bbb_sample (sample 0).
+ * kl_scale_dev, if not NULL, is a device scalar that overrides kl_scale (avoids a host sync when the
+ * scale arrives as an autograd gradient).
+ */
+int snn_bbb_backward(const snn_cfg *cfg, const float *mu, const float *rho, const float *eps, int32_t mode,
+                     uint64_t seed, uint64_t offset, const snn_prior *prior, const float *kl_terms,
+                     float kl_scale, const float *kl_scale_dev, const float *dw, float *dmu, float *drho,
+                     int32_t accumulate, void *stream);
+
+/*
+ * Mean cross-entropy over n curves and dlogits = grad_scale * (softmax - onehot)  [grad_scale = 1/n
+ * for the plain mean]; nn.CrossEntropyLoss at utils/training_utils.py:515 and its backward.
+ * target int64 (n), loss: device scalar.
+ */
+int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float *logits, const int64_t *target,
+                     float grad_scale, float *loss, float *dlogits, void *stream);
+
+
+/*
+ * Fused Adam step over one flat buffer, torch.optim.Adam semantics (betas, eps, L2 weight_decay
+ * added to the gradient; utils/training_utils.py:365-369, :524).  grads are multiplied by
+ * grad_scale first (1/world_size after a data-parallel sum).  step counts from 1.
+ */
+int snn_adam_step(int64_t n, float *params, const float *grads, float *exp_avg, float *exp_avg_sq,
+                  int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ class SnnMasks(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int32), ("which", ctypes.c_int32), ("mid_T", ctypes.c_int32),
                 ("keep_scale", ctypes.c_float), ("keep_prob", ctypes.c_float),
                 ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+                ("curve_base", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
                 ("m_in", ctypes.c_void_p), ("m_whh", ctypes.c_void_p),
                 ("m_mid", ctypes.c_void_p), ("m_out", ctypes.c_void_p)]
 
@@ -63,6 +64,18 @@ SIGNATURES = {
                                         ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64,
                                         _P, ctypes.c_int64, _P]),
+    "snn_train_tape_floats": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
+    "snn_lstm_forward_train": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, _P, ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64,
+                                              _P, ctypes.c_int64, _P]),
+    "snn_lstm_backward_workspace_bytes": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
+    "snn_lstm_backward": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         _P, ctypes.POINTER(SnnMasks), _P, ctypes.c_int64, _P, _P, ctypes.c_int32,
+                                         _P, ctypes.c_int64, _P]),
+    "snn_bbb_backward": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
+                                        ctypes.POINTER(SnnPrior), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_int32, _P]),
+    "snn_ce_loss_grad": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, _P, ctypes.c_float, _P, _P, _P]),
+    "snn_adam_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 6 + [_P]),
 }
 
 _lib = None

@@ -12,8 +12,7 @@
 #include <vector>
 
 #include "../../include/snn_hip.h"
-#include "snn_device.h"
-#include "snn_layout.h"
+#include "snn_kernels.h"
 #include "snn_host.h"
 
 // ============================================================================
@@ -155,14 +154,17 @@ __global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const floa
         p1 = block_sum(p1, sh);
         p2 = block_sum(p2, sh);
         if (threadIdx.x == 0) {
-            float term = 0.0f;
+            float term = 0.0f, r1 = 0.0f, r2 = 0.0f;
             if (sampled) {
                 const float m1 = (float)p1 + logf(prior.pi), m2 = (float)p2 + logf(1.0f - prior.pi);
                 const float mx = fmaxf(m1, m2);
                 const float lse = mx + logf(expf(m1 - mx) + expf(m2 - mx));
                 term = (float)q - lse;
+                r1 = expf(m1 - lse);  // mixture responsibilities: d logsumexp / d m_k (used by snn_bbb_backward)
+                r2 = expf(m2 - lse);
             }
-            kl_terms[(int64_t)s * y.n_tensors + tau] = term;
+            float* o = kl_terms + ((int64_t)s * y.n_tensors + tau) * 3;
+            o[0] = term; o[1] = r1; o[2] = r2;
         }
     }
 }
@@ -173,7 +175,7 @@ __global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ te
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     float acc = 0.0f;
-    for (int t = 0; t < n_tensors; ++t) acc = __fadd_rn(acc, terms[(int64_t)s * n_tensors + t]);
+    for (int t = 0; t < n_tensors; ++t) acc = __fadd_rn(acc, terms[((int64_t)s * n_tensors + t) * 3]);
     kl[s] = acc;
 }
 
@@ -190,11 +192,7 @@ struct FwdParams {
     int n_curves, n_tiles, max_T, n_samples;
     const float* wk;
     int64_t wk_stride;
-    // masks
-    int mask_mode, mask_which, mid_T;
-    float keep_scale, keep_prob;
-    uint64_t seed, offset;
-    const float *m_in, *m_whh, *m_mid, *m_out;
+    MaskP mk;
     // outputs
     float* out_logits;
     float* out_probs;
@@ -204,14 +202,10 @@ struct FwdParams {
     float* yscratch;       // [grid][nbuf][dirs][max_T][H*32]
     int64_t y_buf_floats;  // dirs*max_T*H*32
     int nbuf;
+    // training tape (TRAIN kernels only): [n_tiles][tape_tile_floats]
+    float* tape;
+    int64_t tape_tile;
 };
-
-// LDS-only barrier: global stores of the step stay in flight (they are only
-// read after the phase-end __syncthreads()).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 template <int H, int KKI, int DIRS>
 struct PhaseCfg {
@@ -226,24 +220,27 @@ struct ItemCtx {
     int len, orig;          // of this lane's curve
     const float* wks;       // weight set of this sample
     float* ybase;           // this workgroup's y scratch
+    float* tape;            // TRAIN: this tile's tape
 };
 
 // One (layer, direction) pass over the tile's T steps.
-//   FIRST: input comes from the packed x tile; else from the previous layer's y buffer.
-template <int H, int KKI, int DIRS, bool FIRST>
-__device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, float* smem, int l, int d,
-                                          int k_A, int k_bias, int k_head_w, float* xin, float* hb, float* part,
-                                          float* logit)
+//   FIRST: input comes from the packed x tile; else from the previous layer's output.
+//   TRAIN: activations go to the tape (which also carries the layer outputs, unmasked; the
+//          between-layer mask is then applied by the consumer while staging).
+template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN>
+__device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
+                                          int k_head_w, float* xin, float* hb, float* part, float* logit)
 {
     using PC = PhaseCfg<H, KKI, DIRS>;
     constexpr int NT = PC::NT, NPT = PC::NPT, NF4 = PC::NF4, KKH = H / 2, KK = KKI + KKH;
     constexpr int XIN_STRIDE = PC::ROWS * 32;  // floats per xin buffer for this phase
+    constexpr int NW = H / 8;
     const FwdParams& y = p;  // D, L, C, pool, F
+    const MaskP& mk = p.mk;
     const int ld = l * DIRS + d;
     const bool last_layer = l == y.L - 1;
     const int T = c.T;
-    (void)smem;
-    constexpr int NW = H / 8;
+    const bool masked = mk.mode != SNN_MASK_NONE;
 
     // ---- weights -> registers (A operand of every MFMA of this phase)
     float wreg[KK];
@@ -253,16 +250,9 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         for (int kk = 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];
     }
     // variational W_hh row mask: forward direction only (variational_rnn.py:45, 224-238)
-    if (d == 0 && p.mask_mode != SNN_MASK_NONE) {
+    if (d == 0 && masked) {
         const int r = c.lane & 31;
-        const int R = (r >> 3) * H + 8 * c.w + (r & 7);
-        float m = 1.0f;
-        if (p.mask_mode == SNN_MASK_ARRAYS) {
-            if (p.m_whh) m = p.m_whh[((int64_t)c.s * y.L + l) * 4 * H + R];
-        } else if (p.mask_which & 2) {
-            m = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_WHH, (uint32_t)R, (uint32_t)l, p.keep_prob,
-                            p.keep_scale);
-        }
+        const float m = mask_whh(mk, c.s, y.L, H, l, (r >> 3) * H + 8 * c.w + (r & 7));
 #pragma unroll
         for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
     }
@@ -276,31 +266,19 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     // ---- per-lane masks
     const int j0 = 8 * c.w + 4 * c.hf;  // first of this lane's 4 hidden units
     float mmid[4] = {1.f, 1.f, 1.f, 1.f};
-    bool mid_step = false;
-    if (!last_layer && p.mask_mode != SNN_MASK_NONE && c.orig >= 0) {
-        if (p.mask_mode == SNN_MASK_ARRAYS) {
-            if (p.m_mid) {
-                if (p.mid_T > 1) mid_step = true;
-                else {
-                    const float* M = p.m_mid + (((int64_t)c.s * (y.L - 1) + l) * p.n_curves + c.orig) * (DIRS * H) + d * H + j0;
+    const bool mid_step = masked && mk.mid_T > 1;  // per-step between-layer mask (torch.nn.LSTM dropout, train)
+    if (!TRAIN && !last_layer && masked && c.orig >= 0 && !mid_step) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) mmid[u] = M[u];
-                }
-            }
-        } else if (p.mask_which & 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                mmid[u] = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_MID, (uint32_t)c.orig,
-                                      (uint32_t)(l * DIRS * H + d * H + j0 + u), p.keep_prob, p.keep_scale);
-        }
+        for (int u = 0; u < 4; ++u)
+            mmid[u] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, c.orig, d * H + j0 + u);
     }
-    // input-mask registers of the staging threads (layer 0 only)
+    // mask registers of the staging threads: layer 0 input mask, or (TRAIN) the between-layer mask
     float min_[NPT][4];
 #pragma unroll
     for (int i = 0; i < NPT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
-    if (FIRST && p.mask_mode != SNN_MASK_NONE) {
+    if (masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
@@ -309,13 +287,9 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                    if (o >= 0 && k < y.D) {
-                        if (p.mask_mode == SNN_MASK_ARRAYS) {
-                            if (p.m_in) min_[i][e] = p.m_in[((int64_t)c.s * p.n_curves + o) * y.D + k];
-                        } else if (p.mask_which & 1) {
-                            min_[i][e] = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_IN, (uint32_t)o,
-                                                     (uint32_t)k, p.keep_prob, p.keep_scale);
-                        }
+                    if (o >= 0) {
+                        if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
+                        else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
                     }
                 }
             }
@@ -323,10 +297,13 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     }
 
     // ---- input source
-    const float* in0;  // FIRST: tile base; else y buffer of layer l-1
+    const float* in0;  // FIRST: tile base; TRAIN: tape; else y buffer of layer l-1
     if (FIRST) in0 = p.xp + p.tile_off[c.tile];
+    else if (TRAIN) in0 = c.tape;
     else in0 = c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
-    float* yout = last_layer ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+    float* yout = (last_layer || TRAIN) ? nullptr
+                                        : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+    float* tape_ld = TRAIN ? c.tape + (int64_t)ld * p.max_T * tape_step_floats(H) : nullptr;
 
     auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
 #pragma unroll
@@ -337,21 +314,33 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
                 if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
                 else {
                     const int dd = f / (H * 8), ff = f - dd * (H * 8);
-                    src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
+                    if (TRAIN)
+                        src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
+                    else
+                        src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
                 }
                 pre[i] = *reinterpret_cast<const f32x4*>(src);
             }
         }
     };
-    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT]) {
+    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT], int t) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
             if (f < NF4) {
                 f32x4 v = pre[i];
-                if (FIRST) {
+                if (FIRST || TRAIN) {
+                    if (!FIRST && mid_step) {
+                        const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                            if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                    }
                 }
                 *reinterpret_cast<f32x4*>(dstbuf + f * 4) = v;
             }
@@ -362,8 +351,9 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f}, hsum[4] = {0.f, 0.f, 0.f, 0.f};
     {
         f32x4 pre[NPT];
-        load_step(d == 0 ? 0 : T - 1, pre);
-        store_step(xin, pre);
+        const int t0 = d == 0 ? 0 : T - 1;
+        load_step(t0, pre);
+        store_step(xin, pre, t0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) hb[(j0 + u) * 32 + c.cl] = 0.0f;
     }
@@ -374,7 +364,8 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         const int cur = step & 1;
         f32x4 pre[NPT];
         const bool more = step + 1 < T;
-        if (more) load_step(d == 0 ? t + 1 : t - 1, pre);
+        const int tn = d == 0 ? t + 1 : t - 1;
+        if (more) load_step(tn, pre);
 
         f32x16 acc = binit;
         const float* xc = xin + cur * XIN_STRIDE + c.lane;
@@ -389,6 +380,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         const bool valid = t < c.len;
         float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
         float outv[4];
+        float* tp = TRAIN ? tape_ld + (int64_t)t * tape_step_floats(H) + j0 * 32 + c.cl : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float ig = snn_sigmoid(acc[u]);
@@ -401,22 +393,30 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             hst[u] = valid ? hv : hst[u];
             outv[u] = valid ? hv : 0.0f;
             hn[u * 32] = hst[u];
+            if (TRAIN) {
+                tp[(0 * H + u) * 32] = ig;
+                tp[(1 * H + u) * 32] = fg;
+                tp[(2 * H + u) * 32] = gg;
+                tp[(3 * H + u) * 32] = og;
+                tp[(4 * H + u) * 32] = cn;
+                tp[(5 * H + u) * 32] = outv[u];
+            }
         }
         if (last_layer) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) hsum[u] += outv[u];
-        } else {
+        } else if (!TRAIN) {
             float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
             if (mid_step && c.orig >= 0) {
-                const float* M = p.m_mid + ((((int64_t)c.s * (y.L - 1) + l) * p.mid_T + t) * p.n_curves + c.orig) * (DIRS * H) + d * H + j0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(M[u], outv[u]);
+                for (int u = 0; u < 4; ++u)
+                    yo[u * 32] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, t, c.orig, d * H + j0 + u), outv[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mmid[u], outv[u]);
             }
         }
-        if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre);
+        if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
         lds_barrier();
     }
 
@@ -435,18 +435,14 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
                 fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
             }
         }
-        if (p.mask_mode != SNN_MASK_NONE && c.orig >= 0) {
+        if (masked && c.orig >= 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float m = 1.0f;
-                if (p.mask_mode == SNN_MASK_ARRAYS) {
-                    if (p.m_out) m = p.m_out[((int64_t)c.s * p.n_curves + c.orig) * y.F + fidx[u]];
-                } else if (p.mask_which & 8) {
-                    m = philox_mask(p.seed, p.offset + c.s, SNN_STREAM_MASK_OUT, (uint32_t)c.orig, (uint32_t)fidx[u],
-                                    p.keep_prob, p.keep_scale);
-                }
-                feat[u] = __fmul_rn(m, feat[u]);
-            }
+            for (int u = 0; u < 4; ++u) feat[u] = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, c.orig, fidx[u]), feat[u]);
+        }
+        if (TRAIN) {
+            float* fs = c.tape + (int64_t)y.L * DIRS * p.max_T * tape_step_floats(H);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fs[fidx[u] * 32 + c.cl] = feat[u];
         }
         const float* Wo = c.wks + k_head_w;
         for (int q = 0; q < y.C; ++q) {
@@ -464,10 +460,10 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             logit[idx] = a;
         }
     }
-    __syncthreads();  // also publishes this phase's y stores to the workgroup
+    __syncthreads();  // also publishes this phase's y / tape stores to the workgroup
 }
 
-template <int H, int KKI0, int DIRS>
+template <int H, int KKI0, int DIRS, bool TRAIN>
 __global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
 {
     constexpr int NT = H * 8;
@@ -507,6 +503,7 @@ __global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
         c.len = p.len_sorted[pos];
         c.orig = p.order[pos];
         c.wks = p.wk + (int64_t)c.s * p.wk_stride;
+        c.tape = TRAIN ? p.tape + (int64_t)c.tile * p.tape_tile : nullptr;
         for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
         __syncthreads();  // item_slot consumed, logit zeroed
 
@@ -514,12 +511,12 @@ __global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    run_phase<H, KKI0, DIRS, true>(p, c, smem, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin,
-                                                   hb, part, logit);
+                    run_phase<H, KKI0, DIRS, true, TRAIN>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin,
+                                                          hb, part, logit);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    run_phase<H, KKI1, DIRS, false>(p, c, smem, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin,
-                                                    hb, part, logit);
+                    run_phase<H, KKI1, DIRS, false, TRAIN>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin,
+                                                           hb, part, logit);
                 }
             }
         }
@@ -592,8 +589,8 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 
 // ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn; };
-#define FWD_ENTRY(H, K, Dd) {H, K, Dd, lstm_fwd_kernel<H, K, Dd>}
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_train; };
+#define FWD_ENTRY(H, K, Dd) {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false>, lstm_fwd_kernel<H, K, Dd, true>}
 static const FwdEntry g_fwd[] = {
     FWD_ENTRY(32, 12, 2),  // D = 23..24  (4 filters)
     FWD_ENTRY(32, 13, 2),  // D = 25..26  (4 filters + redshift)
@@ -730,7 +727,7 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 // ---- persistent forward launch geometry ------------------------------------
 struct FwdGeom { int grid, nbuf; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
-static int fwd_geom(const SnnLayout& y, const FwdEntry* e, int max_T, FwdGeom* g)
+static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, int max_T, FwdGeom* g)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
     g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
@@ -745,8 +742,8 @@ static int fwd_geom(const SnnLayout& y, const FwdEntry* e, int max_T, FwdGeom* g
         cached_dev = dev;
     }
     int per_cu = 0;
-    HIP_CHECK(hipFuncSetAttribute((const void*)e->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)e->fn, y.H * 8, g->lds));
+    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, y.H * 8, g->lds));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     g->grid = cached_cus * per_cu;
@@ -764,17 +761,41 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     const FwdEntry* e = find_fwd(y);
     if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
-    FwdGeom g;
-    rc = fwd_geom(y, e, max_T, &g);
-    return rc ? rc : g.ws_bytes;
+    FwdGeom g, gt;
+    rc = fwd_geom(y, e->fn, max_T, &g);
+    if (!rc) rc = fwd_geom(y, e->fn_train, max_T, &gt);
+    return rc ? rc : std::max(g.ws_bytes, gt.ws_bytes);
 }
 
-extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
-                                const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
-                                int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
-                                int64_t wk_sample_stride, int32_t n_samples, const snn_masks* masks,
-                                float* out_logits, float* out_probs, int64_t out_stride_sample,
-                                int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream)
+int snn_masks_to_device(const snn_masks* masks, int max_T, MaskP* mk)
+{
+    memset(mk, 0, sizeof(*mk));
+    if (!masks || masks->mode == SNN_MASK_NONE) return SNN_OK;
+    if (masks->mode != SNN_MASK_ARRAYS && masks->mode != SNN_MASK_PHILOX) {
+        snn_set_error("masks.mode %d invalid", masks->mode);
+        return SNN_ERR_ARG;
+    }
+    if (masks->mid_T != 1 && masks->mid_T != max_T && (masks->mode == SNN_MASK_PHILOX || masks->mid)) {
+        snn_set_error("masks.mid_T must be 1 or max_T (%d), got %d", max_T, masks->mid_T);
+        return SNN_ERR_ARG;
+    }
+    if (masks->mode == SNN_MASK_PHILOX && !(masks->keep_prob > 0.f && masks->keep_prob <= 1.f)) {
+        snn_set_error("masks.keep_prob out of (0,1]");
+        return SNN_ERR_ARG;
+    }
+    mk->mode = masks->mode; mk->which = masks->which; mk->mid_T = masks->mid_T < 1 ? 1 : masks->mid_T;
+    mk->keep_scale = masks->keep_scale; mk->keep_prob = masks->keep_prob;
+    mk->seed = masks->seed; mk->offset = masks->offset; mk->curve_base = masks->curve_base;
+    mk->m_in = masks->in; mk->m_whh = masks->whh; mk->m_mid = masks->mid; mk->m_out = masks->out;
+    return SNN_OK;
+}
+
+static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const int32_t* len_sorted,
+                          const int32_t* order, const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves,
+                          int32_t n_tiles, int32_t max_T, const float* wk, int64_t wk_sample_stride,
+                          int32_t n_samples, const snn_masks* masks, float* out_logits, float* out_probs,
+                          int64_t out_stride_sample, int64_t out_stride_curve, float* tape, int64_t tape_floats,
+                          void* workspace, int64_t workspace_bytes, void* stream)
 {
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
@@ -792,8 +813,15 @@ extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32
                       n_tiles, max_T, n_samples);
         return SNN_ERR_ARG;
     }
+    const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
+    if (train && (!tape || n_samples != 1 || tape_floats < tape_tile * n_tiles)) {
+        snn_set_error("snn_lstm_forward_train: tape missing or too small (%lld < %lld floats) or n_samples != 1",
+                      (long long)tape_floats, (long long)(tape_tile * n_tiles));
+        return SNN_ERR_ARG;
+    }
+    fwd_kernel_t fn = train ? e->fn_train : e->fn;
     FwdGeom g;
-    rc = fwd_geom(y, e, max_T, &g);
+    rc = fwd_geom(y, fn, max_T, &g);
     if (rc) return rc;
     if (workspace_bytes < g.ws_bytes) {
         snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
@@ -805,35 +833,51 @@ extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32
     p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
     p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
     p.wk = wk; p.wk_stride = wk_sample_stride;
-    if (masks && masks->mode != SNN_MASK_NONE) {
-        if (masks->mode == SNN_MASK_ARRAYS) {
-            if (masks->mid && masks->mid_T != 1 && masks->mid_T != max_T) {
-                snn_set_error("snn_lstm_forward: masks.mid_T must be 1 or max_T");
-                return SNN_ERR_ARG;
-            }
-        } else if (masks->mode == SNN_MASK_PHILOX) {
-            if (!(masks->keep_prob > 0.f && masks->keep_prob <= 1.f)) {
-                snn_set_error("snn_lstm_forward: masks.keep_prob out of (0,1]");
-                return SNN_ERR_ARG;
-            }
-        } else {
-            snn_set_error("snn_lstm_forward: masks.mode %d invalid", masks->mode);
-            return SNN_ERR_ARG;
-        }
-        p.mask_mode = masks->mode; p.mask_which = masks->which; p.mid_T = masks->mid ? masks->mid_T : 1;
-        p.keep_scale = masks->keep_scale; p.keep_prob = masks->keep_prob; p.seed = masks->seed; p.offset = masks->offset;
-        p.m_in = masks->in; p.m_whh = masks->whh; p.m_mid = masks->mid; p.m_out = masks->out;
-    }
+    rc = snn_masks_to_device(masks, max_T, &p.mk);
+    if (rc) return rc;
     p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
     p.counter = (unsigned int*)workspace;
     p.yscratch = (float*)((char*)workspace + 256);
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
+    p.tape = tape; p.tape_tile = tape_tile;
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
     const int64_t n_items = (int64_t)n_tiles * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
-    hipLaunchKernelGGL(e->fn, dim3(grid), dim3(y.H * 8), g.lds, st, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(y.H * 8), g.lds, st, p);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
+}
+
+extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
+                                const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
+                                int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
+                                int64_t wk_sample_stride, int32_t n_samples, const snn_masks* masks,
+                                float* out_logits, float* out_probs, int64_t out_stride_sample,
+                                int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    return launch_forward(cfg, false, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk,
+                          wk_sample_stride, n_samples, masks, out_logits, out_probs, out_stride_sample,
+                          out_stride_curve, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int64_t snn_train_tape_floats(const snn_cfg* cfg, int32_t n_tiles, int32_t max_T)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_train_tape_floats: bad sizes"); return SNN_ERR_ARG; }
+    return tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F) * n_tiles;
+}
+
+extern "C" int snn_lstm_forward_train(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
+                                      const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
+                                      int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
+                                      const snn_masks* masks, float* out_logits, float* tape, int64_t tape_floats,
+                                      void* workspace, int64_t workspace_bytes, void* stream)
+{
+    return launch_forward(cfg, true, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, 0, 1,
+                          masks, out_logits, nullptr, 0, cfg ? cfg->nb_classes : 0, tape, tape_floats, workspace,
+                          workspace_bytes, stream);
 }

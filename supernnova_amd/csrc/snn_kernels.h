@@ -1,0 +1,81 @@
+// snn_kernels.h -- structures and device helpers shared by the forward and the
+// training kernels (mask evaluation, barriers, tape layout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/snn_hip.h"
+#include "snn_device.h"
+#include "snn_layout.h"
+
+// Dropout masks as the kernels see them (host: snn_masks).
+struct MaskP {
+    int mode, which, mid_T;
+    float keep_scale, keep_prob;
+    uint64_t seed, offset;
+    uint32_t curve_base;
+    const float *m_in, *m_whh, *m_mid, *m_out;
+};
+
+// All four return 1.0 when the mask does not exist.  `s` = MC sample, `orig` = original curve index.
+__device__ __forceinline__ float mask_in(const MaskP& m, int s, int n_curves, int D, int orig, int k)
+{
+    if (m.mode == SNN_MASK_ARRAYS) return m.m_in ? m.m_in[((int64_t)s * n_curves + orig) * D + k] : 1.0f;
+    if (m.mode == SNN_MASK_PHILOX && (m.which & 1))
+        return philox_mask(m.seed, m.offset + s, SNN_STREAM_MASK_IN, m.curve_base + (uint32_t)orig, (uint32_t)k,
+                           m.keep_prob, m.keep_scale);
+    return 1.0f;
+}
+__device__ __forceinline__ float mask_whh(const MaskP& m, int s, int L, int H, int l, int R)
+{
+    if (m.mode == SNN_MASK_ARRAYS) return m.m_whh ? m.m_whh[((int64_t)s * L + l) * 4 * H + R] : 1.0f;
+    if (m.mode == SNN_MASK_PHILOX && (m.which & 2))
+        return philox_mask(m.seed, m.offset + s, SNN_STREAM_MASK_WHH, (uint32_t)R, (uint32_t)l, m.keep_prob,
+                           m.keep_scale);
+    return 1.0f;
+}
+// feature = index inside the dirs*H output of layer l (the input of layer l+1); t ignored for locked masks
+__device__ __forceinline__ float mask_mid(const MaskP& m, int s, int L, int n_curves, int dirsH, int l, int t,
+                                          int orig, int feature)
+{
+    if (m.mode == SNN_MASK_ARRAYS) {
+        if (!m.m_mid) return 1.0f;
+        const int tt = m.mid_T > 1 ? t : 0;
+        return m.m_mid[((((int64_t)s * (L - 1) + l) * m.mid_T + tt) * n_curves + orig) * dirsH + feature];
+    }
+    if (m.mode == SNN_MASK_PHILOX && (m.which & 4)) {
+        const uint32_t tkey = m.mid_T > 1 ? (uint32_t)(t + 1) : 0u;
+        return philox_mask(m.seed, m.offset + s, SNN_STREAM_MASK_MID, m.curve_base + (uint32_t)orig,
+                           (uint32_t)(l * dirsH + feature) | (tkey << 16), m.keep_prob, m.keep_scale);
+    }
+    return 1.0f;
+}
+__device__ __forceinline__ float mask_out(const MaskP& m, int s, int n_curves, int F, int orig, int fidx)
+{
+    if (m.mode == SNN_MASK_ARRAYS) return m.m_out ? m.m_out[((int64_t)s * n_curves + orig) * F + fidx] : 1.0f;
+    if (m.mode == SNN_MASK_PHILOX && (m.which & 8))
+        return philox_mask(m.seed, m.offset + s, SNN_STREAM_MASK_OUT, m.curve_base + (uint32_t)orig, (uint32_t)fidx,
+                           m.keep_prob, m.keep_scale);
+    return 1.0f;
+}
+
+// LDS-only barrier: global stores of the step stay in flight (they are only
+// read after a later __syncthreads()).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- training tape -----------------------------------------------------------
+// Written by the training forward, read by the backward.  Per tile:
+//   tape[ld][t][q][H][32]   q: 0 i, 1 f, 2 g, 3 o (post-activation), 4 c_t, 5 h_t (0 beyond the curve, unmasked)
+//   then feat[F][32] (pooled features after the output mask), then logits are the regular output.
+#define SNN_TAPE_Q 6
+__host__ __device__ inline int64_t tape_step_floats(int H) { return (int64_t)SNN_TAPE_Q * H * 32; }
+__host__ __device__ inline int64_t tape_tile_floats(int H, int n_ld, int max_T, int F)
+{
+    return (int64_t)n_ld * max_T * tape_step_floats(H) + (int64_t)F * 32;
+}
+
+// host-side mask validation / conversion (snn_forward.hip)
+int snn_masks_to_device(const snn_masks* masks, int max_T, MaskP* out);

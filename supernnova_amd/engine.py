@@ -186,7 +186,7 @@ def bbb_sample(cfg, mu, rho, n_samples, prior, eps=None, mean_field=False, seed=
     kl = terms = None
     if want_kl:
         kl = torch.empty(n_samples, dtype=torch.float32, device=mu.device)
-        terms = torch.empty(n_samples * cfg.n_tensors, dtype=torch.float32, device=mu.device)
+        terms = torch.empty(n_samples * cfg.n_tensors * 3, dtype=torch.float32, device=mu.device)
     pr = prior.c
     L.check(L.load().snn_bbb_sample(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset,
                                     n_samples, ctypes.byref(pr), _ptr(wk), _ptr(kl), _ptr(terms), _stream()),
@@ -207,11 +207,13 @@ class Masks:
     dropout: float = 0.0
     seed: int = 0
     offset: int = 0
+    curve_base: int = 0
 
     def c(self):
         keep = 1.0 - self.dropout
         scale = float(np.float32(1.0) / np.float32(keep)) if keep > 0 else 0.0
         return L.SnnMasks(self.mode, self.which, self.mid_T, scale, keep, self.seed, self.offset,
+                          self.curve_base, 0,
                           *(None if m is None else m.data_ptr() for m in (self.m_in, self.m_whh, self.m_mid, self.m_out)))
 
 
@@ -274,3 +276,108 @@ def lstm_forward(cfg, plan, xp, wk, n_samples, masks=None, want_logits=True, wan
         ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(probs), os_s, os_n,
         _ptr(ws), ws.numel(), _stream()), "snn_lstm_forward")
     return logits, probs
+
+
+# ----------------------------------------------------------------------------- training
+def lstm_forward_train(cfg, plan, xp, wk, masks=None):
+    """Training forward of one weight set. Returns (logits (N,C) original order, tape)."""
+    _require_cuda(xp, "xp")
+    _require_cuda(wk, "wk")
+    dev = xp.device
+    if wk.numel() != cfg.PK:
+        raise L.SnnError("training forward takes exactly one weight set (PK floats)")
+    n_tape = L.check(L.load().snn_train_tape_floats(ctypes.byref(cfg.c), plan.n_tiles, plan.max_T),
+                     "snn_train_tape_floats")
+    tape = torch.empty(n_tape, dtype=torch.float32, device=dev)
+    logits = torch.empty((plan.n_curves, cfg.nb_classes), dtype=torch.float32, device=dev)
+    mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
+    ws = _workspace(cfg, plan.max_T, dev)
+    L.check(L.load().snn_lstm_forward_train(
+        ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
+        _ptr(plan.d_tile_off), plan.n_curves, plan.n_tiles, plan.max_T, _ptr(wk),
+        ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(tape), tape.numel(),
+        _ptr(ws), ws.numel(), _stream()), "snn_lstm_forward_train")
+    return logits, tape
+
+
+_bwd_workspaces = {}
+
+
+def lstm_backward(cfg, plan, xp, wk, tape, dlogits, masks=None, out=None, accumulate=False):
+    """BPTT: dlogits (N,C) -> gradient w.r.t. the weight set, canonical flat (P,)."""
+    _require_cuda(dlogits, "dlogits")
+    dev = xp.device
+    if tuple(dlogits.shape) != (plan.n_curves, cfg.nb_classes):
+        raise L.SnnError(f"dlogits shape {tuple(dlogits.shape)} != ({plan.n_curves},{cfg.nb_classes})")
+    need = L.check(L.load().snn_lstm_backward_workspace_bytes(ctypes.byref(cfg.c), plan.n_tiles, plan.max_T),
+                   "snn_lstm_backward_workspace_bytes")
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _bwd_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _bwd_workspaces[key] = ws
+    if out is None:
+        out = torch.empty(cfg.P, dtype=torch.float32, device=dev)
+        accumulate = False
+    mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
+    L.check(L.load().snn_lstm_backward(
+        ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
+        _ptr(plan.d_tile_off), plan.n_curves, plan.n_tiles, plan.max_T, _ptr(wk),
+        ctypes.byref(mc) if mc is not None else None, _ptr(tape), tape.numel(), _ptr(dlogits), _ptr(out),
+        int(bool(accumulate)), _ptr(ws), ws.numel(), _stream()), "snn_lstm_backward")
+    return out
+
+
+def bbb_sample_train(cfg, mu, rho, prior, eps=None, mean_field=False, seed=0, offset=0):
+    """One draw for training: (wk (PK,), kl 0-dim tensor, kl_terms) -- kl_terms feeds bbb_backward."""
+    Ps = cfg.P - cfg.nb_classes
+    mode = L.BBB_MFE if mean_field else (L.BBB_EPS if eps is not None else L.BBB_PHILOX)
+    if eps is not None:
+        _require_cuda(eps, "eps")
+        if eps.numel() != Ps:
+            raise L.SnnError(f"eps has {eps.numel()} floats, expected {Ps}")
+    wk = torch.empty(cfg.PK, dtype=torch.float32, device=mu.device)
+    kl = torch.empty(1, dtype=torch.float32, device=mu.device)
+    terms = torch.empty(cfg.n_tensors * 3, dtype=torch.float32, device=mu.device)
+    pr = prior.c
+    L.check(L.load().snn_bbb_sample(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset, 1,
+                                    ctypes.byref(pr), _ptr(wk), _ptr(kl), _ptr(terms), _stream()), "snn_bbb_sample")
+    return wk, kl[0], terms, mode
+
+
+def bbb_backward(cfg, mu, rho, prior, terms, dw, mode, eps=None, seed=0, offset=0, kl_scale=0.0, kl_scale_dev=None,
+                 dmu=None, drho=None, accumulate=False):
+    """dCE/dw (P) -> (dmu (P), drho (P-C)) of CE + kl_scale*KL."""
+    dev = mu.device
+    if dmu is None:
+        dmu = torch.empty(cfg.P, dtype=torch.float32, device=dev)
+        drho = torch.empty(cfg.P - cfg.nb_classes, dtype=torch.float32, device=dev)
+        accumulate = False
+    pr = prior.c
+    L.check(L.load().snn_bbb_backward(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset,
+                                      ctypes.byref(pr), _ptr(terms), float(kl_scale), _ptr(kl_scale_dev), _ptr(dw),
+                                      _ptr(dmu), _ptr(drho), int(bool(accumulate)), _stream()), "snn_bbb_backward")
+    return dmu, drho
+
+
+def ce_loss_grad(logits, target, grad_scale=None):
+    """Mean CE over the batch + dlogits = grad_scale*(softmax - onehot) (default 1/N)."""
+    _require_cuda(logits, "logits")
+    N, C = logits.shape
+    if target.dtype != torch.int64 or not target.is_cuda or target.numel() != N:
+        raise L.SnnError("target must be a device int64 tensor with one entry per curve")
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    L.check(L.load().snn_ce_loss_grad(N, C, _ptr(logits), _ptr(target), 1.0 / N if grad_scale is None else grad_scale,
+                                      _ptr(loss), _ptr(dlogits), _stream()), "snn_ce_loss_grad")
+    return loss[0], dlogits
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              grad_scale=1.0):
+    for t, n in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _require_cuda(t, n)
+        if t.numel() != params.numel():
+            raise L.SnnError("adam_step: size mismatch")
+    L.check(L.load().snn_adam_step(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), step,
+                                   lr, betas[0], betas[1], eps, weight_decay, grad_scale, _stream()), "snn_adam_step")
