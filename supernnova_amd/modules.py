@@ -91,24 +91,62 @@ class _HipRNN(nn.Module):
         self.rnn_output_option = settings.rnn_output_option
         self.cfg = E.Config(input_size, self.hidden_size, self.num_layers, self.bidirectional,
                             self.output_size, self.rnn_output_option)
-        self._flat_cache = {}
+        self._pflat = None
+        self.dp_curve_base = 0   # data-parallel: global index of this rank's first curve (per-curve Philox masks)
 
     @property
     def last_input_size(self):
         f = self.hidden_size * _dirs(self.bidirectional)
         return f if self.rnn_output_option == "mean" else f * self.num_layers
 
-    # -- parameters -> canonical flat buffer (cached on parameter versions)
-    def _flat(self, keys, tag):
+    # -- parameters live as views of ONE flat fp32 buffer in kernel-canonical order, so the kernels,
+    #    the fused Adam and the data-parallel all-reduce all see a single contiguous array.
+    def _flat_groups(self):
+        """[(tag, [state_dict keys in canonical order])]; concatenated they define the flat buffer."""
+        raise NotImplementedError
+
+    def _flat_params(self):
         params = dict(self.named_parameters())
-        ps = [params[k] for k in keys]
-        sig = tuple((p.data_ptr(), p._version) for p in ps)
-        hit = self._flat_cache.get(tag)
-        if hit is None or hit[0] != sig:
-            with torch.no_grad():
-                hit = (sig, torch.cat([p.detach().reshape(-1) for p in ps]).float().contiguous())
-            self._flat_cache[tag] = hit
-        return hit[1]
+        return [params[k] for _, keys in self._flat_groups() for k in keys]
+
+    def _flatten(self):
+        ps = self._flat_params()
+        dev = ps[0].device
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps]).contiguous()
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+        self._pflat = flat
+        self._slices, off = {}, 0
+        params = dict(self.named_parameters())
+        for tag, keys in self._flat_groups():
+            n = sum(params[k].numel() for k in keys)
+            self._slices[tag] = (off, off + n)
+            off += n
+        assert off == flat.numel() and dev == flat.device
+
+    def flat_parameters(self):
+        """The flat buffer all parameters are views of (re-flattened if something re-pointed them)."""
+        flat = getattr(self, "_pflat", None)
+        ok = flat is not None
+        if ok:
+            ptr, esz = flat.data_ptr(), flat.element_size()
+            for p in self._flat_params():
+                if p.data_ptr() != ptr or p.device != flat.device:
+                    ok = False
+                    break
+                ptr += p.numel() * esz
+        if not ok:
+            self._flatten()
+        return self._pflat
+
+    def _flat(self, tag):
+        flat = self.flat_parameters()
+        a, b = self._slices[tag]
+        return flat[a:b]
 
     # -- x -> (padded (T,B,D) on device, host lengths)
     def _unpack(self, x):
@@ -136,6 +174,57 @@ class _HipRNN(nn.Module):
     def _seed(self):
         return int(torch.empty((), dtype=torch.int64).random_().item())
 
+    def _use_train_path(self):
+        return self.training and torch.is_grad_enabled()
+
+    def _train_forward(self, x, masks_fn, eps=None, mean_field_inference=False):
+        """Differentiable forward (autograd.Function over the HIP train/backward kernels)."""
+        padded, lengths = self._unpack(x)
+        if not self.cfg.supported():
+            raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
+        self.flat_parameters()
+        return _TrainFn.apply(self, padded, lengths, masks_fn, eps, mean_field_inference, *self._flat_params())
+
+    def fused_train_step(self, x, target, optimizer, kl_scale=0.0, eps=None, masks=None):
+        """One training step without autograd (utils/training_utils.py:508-525 in five launches):
+        forward-train, CE + dlogits, BPTT, (BBB backward), fused Adam.  Returns the loss (device scalar)."""
+        padded, lengths = self._unpack(x)
+        if not self.cfg.supported():
+            raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
+        cfg, dev = self.cfg, padded.device
+        self.flat_parameters()
+        plan = E.Plan(cfg, lengths, dev)
+        xp = E.pack_x(cfg, plan, padded)
+        bayes = isinstance(self, BayesianRNN)
+        if masks is None and not bayes:
+            masks = self._masks(plan) if isinstance(self, VanillaRNN) else \
+                self._masks(1, plan.n_curves, dev, False)
+        if bayes:
+            mu, rho = self._mu_rho()
+            if eps is None and self.draws == "host":
+                eps = self.host_eps(1, dev)
+            seed = 0 if eps is not None else self._seed()
+            if eps is not None:
+                eps = eps.reshape(-1).contiguous()
+            wk, kl, terms, mode = E.bbb_sample_train(cfg, mu, rho, self._prior, eps=eps, seed=seed)
+        else:
+            wk = E.prepare_weights(cfg, self._flat("w"))
+        logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, masks)
+        ce, dlogits = E.ce_loss_grad(logits, target)
+        dw = E.lstm_backward(cfg, plan, xp, wk, tape, dlogits, masks)
+        if bayes:
+            P, Ps = cfg.P, cfg.P - cfg.nb_classes
+            gflat = torch.empty(P + Ps, dtype=torch.float32, device=dev)
+            E.bbb_backward(cfg, mu, rho, self._prior, terms, dw, mode, eps=eps, seed=seed, kl_scale=kl_scale,
+                           dmu=gflat[:P], drho=gflat[P:])
+            self.kl = kl
+            loss = ce + kl * kl_scale
+        else:
+            gflat, loss = dw, ce
+        optimizer.step_flat(gflat)
+        self.last_logits = logits
+        return loss
+
     def _launch(self, x, wk, n_samples, masks=None, want_probs=False):
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
@@ -155,33 +244,36 @@ class VanillaRNN(_HipRNN):
         self.output_dropout_layer = nn.Dropout(self.dropout)
         self.output_layer = nn.Linear(self.last_input_size, self.output_size)
 
-    def _keys(self):
+    def _flat_groups(self):
         from .layout import vanilla_keys
-        return vanilla_keys(self.num_layers, _dirs(self.bidirectional))
+        return [("w", vanilla_keys(self.num_layers, _dirs(self.bidirectional)))]
 
-    def _masks(self, n_curves, lengths_max, device):
-        """train mode only: torch.nn.LSTM's inter-layer dropout + nn.Dropout on the pooled features."""
+    def _masks(self, plan=None, *_):
+        """train mode only: torch.nn.LSTM's per-step inter-layer dropout (vanilla_rnn.py:26-32) and
+        nn.Dropout on the pooled features (:33, :86), drawn in-kernel (Philox)."""
         if not self.training or self.dropout <= 0:
             return None
-        if self.draws == "host":
-            raise L.SnnError("VanillaRNN train-mode host draws are supplied through forward_train()")
         which = (4 if self.num_layers > 1 else 0) | 8
-        return E.Masks(mode=L.SNN_MASK_PHILOX, which=which, dropout=self.dropout, seed=self._seed())
+        return E.Masks(mode=L.SNN_MASK_PHILOX, which=which, dropout=self.dropout, seed=self._seed(),
+                       mid_T=plan.max_T if plan is not None else 1, curve_base=self.dp_curve_base)
 
-    def forward(self, x, mean_field_inference=False):
-        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
-        masks = self._masks(None, None, None)
+    def forward(self, x, mean_field_inference=False, masks=None):
+        if self._use_train_path():
+            fn = (lambda plan: masks) if masks is not None else self._masks
+            logits, _ = self._train_forward(x, fn)
+            return logits
+        wk = E.prepare_weights(self.cfg, self._flat("w"))
         (logits, _), _ = self._launch(x, wk, 1, masks)
         return logits[0]
 
     def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
         """(kernel-layout weights, masks) for n_samples forwards over n_curves curves."""
-        return E.prepare_weights(self.cfg, self._flat(self._keys(), "w")), self._masks(None, None, None)
+        return E.prepare_weights(self.cfg, self._flat("w")), None
 
     def forward_mc(self, x, n_samples=1, mean_field_inference=False):
         """probs (B, n_samples, C); a vanilla model is deterministic in eval mode."""
-        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
-        (_, probs), _ = self._launch(x, wk, n_samples, self._masks(None, None, None), want_probs=True)
+        wk = E.prepare_weights(self.cfg, self._flat("w"))
+        (_, probs), _ = self._launch(x, wk, n_samples, None, want_probs=True)
         return probs.permute(1, 0, 2)
 
 
@@ -196,9 +288,9 @@ class VariationalRNN(_HipRNN):
             setattr(self, f"rnn_layer{i}", _WeightDropParams(I, self.hidden_size, self.bidirectional))
         self.output_layer = nn.Linear(self.last_input_size, self.output_size)
 
-    def _keys(self):
+    def _flat_groups(self):
         from .layout import variational_keys
-        return variational_keys(self.num_layers, _dirs(self.bidirectional))
+        return [("w", variational_keys(self.num_layers, _dirs(self.bidirectional)))]
 
     def host_masks(self, n_samples, n_curves, device):
         """Draw the masks on the host with the reference's calls in the reference's order
@@ -229,27 +321,31 @@ class VariationalRNN(_HipRNN):
             return None
         if self.draws == "host":
             return self.host_masks(n_samples, n_curves, device)
-        return E.Masks(mode=L.SNN_MASK_PHILOX, which=0xF, dropout=self.dropout, seed=self._seed())
+        return E.Masks(mode=L.SNN_MASK_PHILOX, which=0xF, dropout=self.dropout, seed=self._seed(),
+                       curve_base=self.dp_curve_base)
 
     def _n_curves(self, x):
         return int(x.batch_sizes[0]) if isinstance(x, PackedSequence) else x.size(1)
 
     def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
         """(kernel-layout weights, masks) for n_samples MC-dropout forwards over n_curves curves."""
-        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        wk = E.prepare_weights(self.cfg, self._flat("w"))
         return wk, self._masks(n_samples, n_curves, device, mean_field_inference)
 
     def forward(self, x, mean_field_inference=False, masks=None):
-        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
         dev = x.data.device if isinstance(x, PackedSequence) else x.device
         if masks is None:
             masks = self._masks(1, self._n_curves(x), dev, mean_field_inference)
+        if self._use_train_path():
+            logits, _ = self._train_forward(x, lambda plan: masks)
+            return logits
+        wk = E.prepare_weights(self.cfg, self._flat("w"))
         (logits, _), _ = self._launch(x, wk, 1, masks)
         return logits[0]
 
     def forward_mc(self, x, n_samples, mean_field_inference=False, masks=None):
         """All n_samples MC-dropout forwards in one launch -> probs (B, n_samples, C)."""
-        wk = E.prepare_weights(self.cfg, self._flat(self._keys(), "w"))
+        wk = E.prepare_weights(self.cfg, self._flat("w"))
         dev = x.data.device if isinstance(x, PackedSequence) else x.device
         if masks is None:
             masks = self._masks(n_samples, self._n_curves(x), dev, mean_field_inference)
@@ -317,11 +413,13 @@ class BayesianRNN(_HipRNN):
         self.kl = None
         self._draw_count = 0
 
-    def _mu_rho(self):
+    def _flat_groups(self):
         from .layout import bayesian_keys
         dirs = _dirs(self.bidirectional)
-        return (self._flat(bayesian_keys(self.num_layers, dirs, "mu"), "mu"),
-                self._flat(bayesian_keys(self.num_layers, dirs, "rho"), "rho"))
+        return [("mu", bayesian_keys(self.num_layers, dirs, "mu")), ("rho", bayesian_keys(self.num_layers, dirs, "rho"))]
+
+    def _mu_rho(self):
+        return self._flat("mu"), self._flat("rho")
 
     def host_eps(self, n_samples, device):
         """eps drawn like the reference (bayesian_rnn.py:492-523, 608): one CPU normal_ per tensor,
@@ -350,6 +448,11 @@ class BayesianRNN(_HipRNN):
 
     def forward(self, x, mean_field_inference=False, eps=None):
         dev = x.data.device if isinstance(x, PackedSequence) else x.device
+        if self._use_train_path():
+            if eps is None and not mean_field_inference and self.draws == "host":
+                eps = self.host_eps(1, dev)
+            logits, self.kl = self._train_forward(x, lambda plan: None, eps, mean_field_inference)
+            return logits
         wk, kl = self._sample(1, mean_field_inference, eps, dev)
         (logits, _), _ = self._launch(x, wk, 1)
         self.kl = kl[0]
@@ -362,3 +465,59 @@ class BayesianRNN(_HipRNN):
         (_, probs), _ = self._launch(x, wk, n_samples, want_probs=True)
         self.kl = kl
         return probs.permute(1, 0, 2)
+
+
+class _TrainFn(torch.autograd.Function):
+    """logits, kl = f(parameters): forward = snn_bbb_sample/snn_prepare_weights + snn_lstm_forward_train,
+    backward = snn_lstm_backward (+ snn_bbb_backward).  Gradients come back as views of one flat buffer
+    laid out like module.flat_parameters()."""
+
+    @staticmethod
+    def forward(ctx, mod, padded, lengths, masks_fn, eps, mean_field, *params):
+        cfg = mod.cfg
+        dev = padded.device
+        plan = E.Plan(cfg, lengths, dev)
+        xp = E.pack_x(cfg, plan, padded)
+        masks = masks_fn(plan) if masks_fn is not None else None
+        bayes = isinstance(mod, BayesianRNN)
+        ctx.bayes = bayes
+        if bayes:
+            mu, rho = mod._mu_rho()
+            seed = 0 if (mean_field or eps is not None) else mod._seed()
+            if eps is not None:
+                eps = eps.reshape(-1).contiguous()
+            wk, kl, terms, mode = E.bbb_sample_train(cfg, mu, rho, mod._prior, eps=eps, mean_field=mean_field,
+                                                     seed=seed)
+            ctx.bbb = (mu, rho, terms, mode, eps, seed)
+        else:
+            wk = E.prepare_weights(cfg, mod._flat("w"))
+            kl = torch.zeros((), dtype=torch.float32, device=dev)
+        logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, masks)
+        ctx.mod, ctx.plan, ctx.xp, ctx.wk, ctx.tape, ctx.masks = mod, plan, xp, wk, tape, masks
+        ctx.shapes = [p.shape for p in params]
+        return logits, kl
+
+    @staticmethod
+    def backward(ctx, dlogits, dkl):
+        mod, cfg = ctx.mod, ctx.mod.cfg
+        dev = ctx.xp.device
+        if dlogits is None:
+            dlogits = torch.zeros((ctx.plan.n_curves, cfg.nb_classes), dtype=torch.float32, device=dev)
+        dlogits = dlogits.float().contiguous()
+        dw = E.lstm_backward(cfg, ctx.plan, ctx.xp, ctx.wk, ctx.tape, dlogits, ctx.masks)
+        if ctx.bayes:
+            mu, rho, terms, mode, eps, seed = ctx.bbb
+            P, Ps = cfg.P, cfg.P - cfg.nb_classes
+            gflat = torch.empty(P + Ps, dtype=torch.float32, device=dev)
+            if dkl is None:
+                dkl = torch.zeros((), dtype=torch.float32, device=dev)
+            E.bbb_backward(cfg, mu, rho, mod._prior, terms, dw, mode, eps=eps, seed=seed,
+                           kl_scale_dev=dkl.float().contiguous(), dmu=gflat[:P], drho=gflat[P:])
+        else:
+            gflat = dw
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            grads.append(gflat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, None, None, None, *grads)

@@ -28,8 +28,33 @@ def get_model(settings, input_size):
 
 
 def get_optimizer(settings, model):
-    """Adam(lr, weight_decay) as training_utils.py:365-369."""
-    return torch.optim.Adam(model.parameters(), lr=settings.learning_rate, weight_decay=settings.weight_decay)
+    """Adam(lr, weight_decay) as training_utils.py:365-369 -- the fused HIP Adam over the flat buffer."""
+    from ..optim import FusedAdam
+    return FusedAdam(model, lr=settings.learning_rate, weight_decay=settings.weight_decay)
+
+
+def train_step(settings, rnn, packed_tensor, target_tensor, criterion, optimizer, batch_size, num_batches):
+    """Full training step, the reference's sequence (training_utils.py:484-525): train mode, zero grads,
+    forward, CE (+ KL/(num_batches*batch_size) for BayesianRNN), backward, optimizer step.
+    Under torch.distributed each rank passes its shard of the mini-batch and batch_size = the GLOBAL batch
+    size; the optimizer all-reduces (averages) the flat gradient."""
+    rnn.train()
+    optimizer.zero_grad()
+    output = rnn(packed_tensor)
+    loss = criterion(output.squeeze(), target_tensor)
+    if isinstance(rnn, BayesianRNN):
+        loss = loss + rnn.kl / (num_batches * batch_size)
+    loss.backward()
+    optimizer.step()
+    return loss
+
+
+def train_step_fused(settings, rnn, packed_tensor, target_tensor, optimizer, batch_size, num_batches):
+    """Same step without autograd: CE and its gradient in snn_ce_loss_grad, BPTT, BBB backward with the
+    KL scale known on the host, one Adam launch.  Returns the loss as a device scalar."""
+    from .. import engine as E
+    rnn.train()
+    return rnn.fused_train_step(packed_tensor, target_tensor, optimizer, 1.0 / (num_batches * batch_size))
 
 
 def unnormalize_arr(arr, settings):
