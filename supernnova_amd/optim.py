@@ -48,16 +48,13 @@ class FusedAdam:
 
     def step_flat(self, grads):
         """Adam update from a gradient already laid out like model.flat_parameters()."""
-        import torch.distributed as dist
+        from .distributed import allreduce_mean_scale
         g = self.param_groups[0]
         flat = self.model.flat_parameters()
         if grads.numel() != flat.numel():
             raise RuntimeError("FusedAdam: flat gradient size does not match the parameters")
-        scale = 1.0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            # ONE all-reduce of the whole gradient (160-320 KB at H=32): latency-bound over xGMI, so a single call
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.process_group)
-            scale = 1.0 / dist.get_world_size(self.process_group)
+        # ONE all-reduce of the whole gradient (160-320 KB at H=32): latency-bound over xGMI, so a single call
+        scale = allreduce_mean_scale(grads, self.process_group)
         st = self.state
         if st["exp_avg"] is None or st["exp_avg"].numel() != flat.numel() or st["exp_avg"].device != flat.device:
             st["exp_avg"] = torch.zeros_like(flat)
