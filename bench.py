@@ -181,6 +181,13 @@ def main():
         fl = flops_per_pass(cfg, int(lengths_host.astype(np.int64).sum()), N, S)
         k_ms = float(np.mean(kern_ms))
         achieved = fl / (k_ms * 1e-3) / 1e12
+        traffic = None   # PMC bytes per launch of this workload, from the committed rocprofv3 passes (profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len}:
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "light curves/s classified, BayesianRNN 50 MC samples",
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
@@ -190,9 +197,9 @@ def main():
                                    f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                    f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)",
                        "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
-            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel<32,12,2>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel<32,12,2,false,false>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": k_ms, "flop_per_launch": fl},
         }
         if args.cpu_curves > 0 and world == 1:

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnn_hip.so")
+LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # env override: A/B builds
 
 SNN_POOL_MEAN, SNN_POOL_STANDARD = 0, 1
 SNN_MASK_NONE, SNN_MASK_ARRAYS, SNN_MASK_PHILOX = 0, 1, 2

@@ -7,34 +7,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- activations -----------------------------------------------------------
-// v_exp_f32 / v_rcp_f32 based; absolute error ~1e-7 (checked against the oracle
-// in tests/test_gpu_parity.py).  exp(-x) overflowing to +inf gives rcp(inf) = 0.
-__device__ __forceinline__ float snn_exp(float x)
-{
-#ifdef SNN_ACCURATE_MATH
-    return expf(x);
-#else
-    // 2^(x*log2e) with the product's rounding error compensated by an fma
-    const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011e-08f;
-    float ph = x * l2e_hi;
-    float pl = fmaf(x, l2e_hi, -ph) + x * l2e_lo;
-    return __builtin_amdgcn_exp2f(ph) * (1.0f + pl * 0.693147180559945f);
+// SNN_MATH 0 (default): v_exp_f32 / v_rcp_f32, 4-5 instructions per activation.  exp(x) = 2^(x*log2e)
+//   carries a relative error of ~|x|*1e-7 in the exponential, i.e. an ABSOLUTE error <= ~1e-7 in the
+//   sigmoid / tanh value (they saturate where |x| is large); checked against the oracle in the GPU
+//   parity tests (class probabilities within 1e-5 relative).
+// SNN_MATH 1: exponent product compensated by an fma (abs error ~6e-8).   SNN_MATH 2: ocml expf/tanhf.
+#ifndef SNN_MATH
+#define SNN_MATH 0
 #endif
-}
 __device__ __forceinline__ float snn_sigmoid(float x)
 {
-    return __builtin_amdgcn_rcpf(1.0f + snn_exp(-x));
+#if SNN_MATH == 9   // timing ablation only: no transcendental work
+    return x * 0.125f;
+#elif SNN_MATH == 0
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+#elif SNN_MATH == 1
+    const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011e-08f;
+    const float nx = -x, ph = nx * l2e_hi;
+    const float pl = fmaf(nx, l2e_hi, -ph) + nx * l2e_lo;
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ph) * (1.0f + pl * 0.693147180559945f));
+#else
+    return 1.0f / (1.0f + expf(-x));
+#endif
 }
 __device__ __forceinline__ float snn_tanh(float x)
 {
-#ifdef SNN_ACCURATE_MATH
-    return tanhf(x);
+#if SNN_MATH == 9
+    return x * 0.0625f;
+#elif SNN_MATH == 0
+    // 1 - 2/(1 + e^{2x}): e -> inf gives 1, e -> 0 gives -1; cancellation near 0 costs absolute ~6e-8 only
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f)), 1.0f);
+#elif SNN_MATH == 1
+    return fmaf(2.0f, snn_sigmoid(2.0f * x), -1.0f);
 #else
-    // 1 - 2/(1+e^{2x}); for small |x| the cancellation costs absolute 1e-7 only
-    float ax = fabsf(x);
-    float e = snn_exp(-2.0f * ax);                     // in (0, 1]
-    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf(t, x);
+    return tanhf(x);
 #endif
 }
 

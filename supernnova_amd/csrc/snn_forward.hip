@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <numeric>
@@ -14,6 +15,10 @@
 #include "../../include/snn_hip.h"
 #include "snn_kernels.h"
 #include "snn_host.h"
+
+#ifndef SNN_FWD_WAVES
+#define SNN_FWD_WAVES 4  // waves per SIMD the un-masked inference kernels are register-allocated for (A/B: 2/3/4 -> 67.5/67.6/69.4 % of peak)
+#endif
 
 // ============================================================================
 // pack_x: one workgroup per tile, one thread per (t, curve), loop over features
@@ -227,9 +232,9 @@ struct ItemCtx {
 //   FIRST: input comes from the packed x tile; else from the previous layer's output.
 //   TRAIN: activations go to the tape (which also carries the layer outputs, unmasked; the
 //          between-layer mask is then applied by the consumer while staging).
-template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN>
+template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED>
 __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
-                                          int k_head_w, float* xin, float* hb, float* part, float* logit)
+                                          int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
 {
     using PC = PhaseCfg<H, KKI, DIRS>;
     constexpr int NT = PC::NT, NPT = PC::NPT, NF4 = PC::NF4, KKH = H / 2, KK = KKI + KKH;
@@ -240,7 +245,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     const int ld = l * DIRS + d;
     const bool last_layer = l == y.L - 1;
     const int T = c.T;
-    const bool masked = mk.mode != SNN_MASK_NONE;
+    const bool masked = MASKED && mk.mode != SNN_MASK_NONE;
 
     // ---- weights -> registers (A operand of every MFMA of this phase)
     float wreg[KK];
@@ -256,12 +261,12 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
         for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
     }
-    f32x16 binit;
-    {
+    // b_ih + b_hh in C/D register order, parked in LDS (re-read per step: 4 broadcast ds_read_b128)
+    if (c.cl < 16) {
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) binit[i] = B[i] + B[NW * 32 + i];
+        bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
     }
+    const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
 
     // ---- per-lane masks
     const int j0 = 8 * c.w + 4 * c.hf;  // first of this lane's 4 hidden units
@@ -367,7 +372,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         const int tn = d == 0 ? t + 1 : t - 1;
         if (more) load_step(tn, pre);
 
-        f32x16 acc = binit;
+        f32x16 acc = *binit_p;
         const float* xc = xin + cur * XIN_STRIDE + c.lane;
 #pragma unroll
         for (int kk = 0; kk < KKI; ++kk)
@@ -463,8 +468,8 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     __syncthreads();  // also publishes this phase's y / tape stores to the workgroup
 }
 
-template <int H, int KKI0, int DIRS, bool TRAIN>
-__global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
+template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED>
+__global__ void __launch_bounds__(H * 8, (TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) lstm_fwd_kernel(const FwdParams p)
 {
     constexpr int NT = H * 8;
     constexpr int KKI1 = DIRS * H / 2;
@@ -480,7 +485,8 @@ __global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
     float* hb = xin + 2 * ROWS * 32;        // [2][H*32]
     float* part = hb + 2 * H * 32;          // [NW][C][32]
     float* logit = part + (H / 8) * y.C * 32;  // [C][32]
-    int* item_slot = reinterpret_cast<int*>(logit + y.C * 32);
+    float* bl = logit + y.C * 32;               // [NW][2][16] bias image of the running phase
+    int* item_slot = reinterpret_cast<int*>(bl + NW * 32);
 
     ItemCtx c;
     c.tid = threadIdx.x;
@@ -511,12 +517,12 @@ __global__ void __launch_bounds__(H * 8, 2) lstm_fwd_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    run_phase<H, KKI0, DIRS, true, TRAIN>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin,
-                                                          hb, part, logit);
+                    run_phase<H, KKI0, DIRS, true, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w,
+                                                                  xin, hb, part, logit, bl);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    run_phase<H, KKI1, DIRS, false, TRAIN>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin,
-                                                           hb, part, logit);
+                    run_phase<H, KKI1, DIRS, false, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w,
+                                                                   xin, hb, part, logit, bl);
                 }
             }
         }
@@ -589,8 +595,10 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 
 // ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_train; };
-#define FWD_ENTRY(H, K, Dd) {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false>, lstm_fwd_kernel<H, K, Dd, true>}
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; };
+#define FWD_ENTRY(H, K, Dd)                                                                          \
+    {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
+     lstm_fwd_kernel<H, K, Dd, true, true>}
 static const FwdEntry g_fwd[] = {
     FWD_ENTRY(32, 12, 2),  // D = 23..24  (4 filters)
     FWD_ENTRY(32, 13, 2),  // D = 25..26  (4 filters + redshift)
@@ -725,12 +733,12 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 }
 
 // ---- persistent forward launch geometry ------------------------------------
-struct FwdGeom { int grid, nbuf; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
+struct FwdGeom { int grid, nbuf, cus; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
 static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, int max_T, FwdGeom* g)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
-    g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
+    g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     static thread_local int cached_dev = -1, cached_cus = 0;
     int dev = 0;
@@ -747,6 +755,7 @@ static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, int max_T, FwdGeom* g)
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     g->grid = cached_cus * per_cu;
+    g->cus = cached_cus;
     g->nbuf = y.L > 2 ? 2 : 1;
     g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32;
     g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
@@ -763,6 +772,8 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
     FwdGeom g, gt;
     rc = fwd_geom(y, e->fn, max_T, &g);
+    if (!rc) rc = fwd_geom(y, e->fn_masked, max_T, &gt);
+    if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
     if (!rc) rc = fwd_geom(y, e->fn_train, max_T, &gt);
     return rc ? rc : std::max(g.ws_bytes, gt.ws_bytes);
 }
@@ -819,7 +830,8 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                       (long long)tape_floats, (long long)(tape_tile * n_tiles));
         return SNN_ERR_ARG;
     }
-    fwd_kernel_t fn = train ? e->fn_train : e->fn;
+    const bool masked = masks && masks->mode != SNN_MASK_NONE;
+    fwd_kernel_t fn = train ? e->fn_train : masked ? e->fn_masked : e->fn;
     FwdGeom g;
     rc = fwd_geom(y, fn, max_T, &g);
     if (rc) return rc;
