@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--max-len", type=int, default=40)
-    ap.add_argument("--cpu-curves", type=int, default=1280, help="curves of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

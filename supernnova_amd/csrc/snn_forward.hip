@@ -392,7 +392,9 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             const float fg = snn_sigmoid(acc[4 + u]);
             const float gg = snn_tanh(acc[8 + u]);
             const float og = snn_sigmoid(acc[12 + u]);
-            const float cn = fg * cst[u] + ig * gg;
+            // explicit contraction: every copy of the loop body (peeled last step, TRAIN variant) must round the
+            // same way, so a curve's result does not depend on the tile it lands in
+            const float cn = fmaf(fg, cst[u], __fmul_rn(ig, gg));
             const float hv = og * snn_tanh(cn);
             cst[u] = valid ? cn : cst[u];
             hst[u] = valid ? hv : hst[u];

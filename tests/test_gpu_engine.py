@@ -112,3 +112,74 @@ def test_bayesian_vs_oracle_ragged():
         o = oracle.forward(ocfg, x, lengths, np.concatenate([w, mu[P - C:]]))
         _check(lo[s], pr[s], o["logits"], o["probs"])
         assert abs(float(kl[s]) - oracle.kl(ocfg, w, mu[:P - C], sigma)) / abs(float(kl[s])) < 1e-5
+
+
+def _random_model(cfg, seed, scale=0.3):
+    g = np.random.default_rng(seed)
+    return g.uniform(-scale, scale, cfg.P).astype(np.float32)
+
+
+@pytest.mark.parametrize("D,H,L,bidir,C,pool,N,T,min_len", [
+    (24, 32, 1, True, 2, "mean", 40, 12, 1),        # single layer
+    (24, 32, 3, True, 3, "standard", 33, 9, 1),     # three layers (y scratch ping-pong), standard pooling
+    (24, 32, 2, False, 2, "mean", 50, 15, 1),       # unidirectional
+    (23, 32, 2, True, 2, "mean", 31, 10, 2),        # odd D (zero-padded k-step)
+    (25, 64, 2, True, 7, "standard", 20, 8, 1),     # H=64, odd D, 7 classes
+    (24, 32, 2, True, 20, "mean", 64, 40, 40),      # 20 classes, all curves full length
+    (24, 32, 2, True, 2, "mean", 1, 1, 1),          # one curve of one step
+    (24, 32, 2, True, 2, "mean", 97, 300, 250),     # long sequences (T = 300)
+])
+def test_edge_configs_vs_oracle(D, H, L, bidir, C, pool, N, T, min_len):
+    E = _eng()
+    cfg = E.Config(D, H, L, bidir, C, pool)
+    assert cfg.supported()
+    ocfg = oracle.make_cfg(D, H, L, bidir, C, pool)
+    w = _random_model(cfg, 11, 0.3 if T < 100 else 0.15)
+    x, lengths = make_curves(12, N, T, D, min_len=min_len)
+    wk = E.prepare_weights(cfg, _t(w))
+    lo, pr = _run(E, cfg, x, lengths, wk, 1)
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])
+
+
+def test_masks_all_layers_vs_oracle():
+    """Variational masks with L=3 / standard pooling / per-sample masks, vs the oracle."""
+    E = _eng()
+    D, H, L, C, N, T, S = 26, 32, 3, 4, 45, 14, 3
+    cfg = E.Config(D, H, L, True, C, "standard")
+    ocfg = oracle.make_cfg(D, H, L, True, C, "standard")
+    g = np.random.default_rng(3)
+    w = _random_model(cfg, 4)
+    x, lengths = make_curves(5, N, T, D, min_len=1)
+    p = 0.2
+    bern = lambda *s: (g.random(s) < 1 - p).astype(np.float32) / np.float32(1 - p)
+    m_in, m_whh, m_mid, m_out = bern(S, N, D), bern(S, L, 4 * H), bern(S, L - 1, 1, N, 2 * H), bern(S, N, cfg.F)
+    masks = E.Masks(mode=1, m_in=_t(m_in), m_whh=_t(m_whh), m_mid=_t(m_mid), m_out=_t(m_out), mid_T=1)
+    lo, pr = _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(w)), S, masks)
+    for s in range(S):
+        o = oracle.forward(ocfg, x, lengths, w, m_in[s], m_whh[s], m_mid[s], m_out[s])
+        _check(lo[s], pr[s], o["logits"], o["probs"])
+
+
+def test_large_batch_properties():
+    """At a size the oracle cannot cover: (a) permutation equivariance -- shuffling the curves permutes the
+    outputs bit-for-bit (tiling / sorting / scatter are consistent); (b) a sampled subset matches the oracle."""
+    E = _eng()
+    D, H, C, S, N, T = 24, 32, 2, 3, 20011, 40
+    cfg = E.Config(D, H, 2, True, C, "mean")
+    ocfg = oracle.make_cfg(D, H, 2, True, C, "mean")
+    g = np.random.default_rng(8)
+    mu = g.uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    rho = g.uniform(-4, -2, cfg.P - C).astype(np.float32)
+    eps = g.standard_normal((S, cfg.P - C)).astype(np.float32)
+    x, lengths = make_curves(9, N, T, D, min_len=3)
+    wk, _ = E.bbb_sample(cfg, _t(mu), _t(rho), S, E.Prior(), eps=_t(eps))
+    lo, pr = _run(E, cfg, x, lengths, wk, S)
+    perm = g.permutation(N)
+    lo2, pr2 = _run(E, cfg, np.ascontiguousarray(x[:, perm]), lengths[perm], wk, S)
+    assert np.array_equal(pr2, pr[:, perm]) and np.array_equal(lo2, lo[:, perm])
+    sub = g.choice(N, 64, replace=False)
+    for s in range(S):
+        w, _ = oracle.bbb_sample(mu[:cfg.P - C], rho, eps[s])
+        o = oracle.forward(ocfg, np.ascontiguousarray(x[:, sub]), lengths[sub], np.concatenate([w, mu[cfg.P - C:]]))
+        _check(lo[s][sub], pr[s][sub], o["logits"], o["probs"])
