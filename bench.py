@@ -84,6 +84,7 @@ def flops_per_pass(cfg, lengths_sum, n_curves, S):
 
 
 def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves):
+    x_host = np.ascontiguousarray(x_host)
     """Reference call pattern (validate_rnn.py:539-563) on the stock-PyTorch CPU port."""
     from oracle import torch_port as tp
     from supernnova_amd import layout
@@ -116,6 +117,9 @@ def main():
     ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--max-len", type=int, default=40)
+    ap.add_argument("--workload", choices=["des", "elasticc"], default="des",
+                    help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
+                         "(H=128, 6 filters + redshift, 14 classes, 300-step sequences) -- a secondary measurement")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -132,10 +136,20 @@ def main():
 
     from supernnova_amd import engine as E
 
-    cfg = E.Config(24, 32, 2, True, 2, "mean")
+    big = args.workload == "elasticc"
+    if big:
+        cfg = E.Config(78, 128, 2, True, 14, "mean")
+        if args.curves == 1_250_000:
+            args.curves = 8192
+        if args.max_len == 40:
+            args.max_len = 300
+    else:
+        cfg = E.Config(24, 32, 2, True, 2, "mean")
     S, N = args.samples, args.curves
     mu, rho = bayes_init(cfg, 0, dev)
-    x, lengths = synth_curves(N, args.max_len, 4, dev, seed=1000 + rank)
+    x, lengths = synth_curves(N, args.max_len, 6 if big else 4, dev, seed=1000 + rank, redshift=big)
+    if big:
+        lengths.fill_(args.max_len)      # exactly 300 steps for config 5
     lengths_host = lengths.cpu().numpy()
     prior = E.Prior()
     torch.cuda.synchronize()
@@ -193,11 +207,15 @@ def main():
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BayesianRNN (BBB) LSTM 32x2 bidirectional, mean pooling, D=24 (4 filters), "
-                                   f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
-                                   f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)",
+            "config": {"workload": (f"BayesianRNN (BBB) LSTM 128x2 bidirectional, mean pooling, D=78 (6 filters + redshift), "
+                                    f"C=14, S={S} MC samples, {args.max_len}-step sequences, {N} light curves per GPU "
+                                    "(configs[4], ELAsTiCC-like)") if big else
+                                   ("BayesianRNN (BBB) LSTM 32x2 bidirectional, mean pooling, D=24 (4 filters), "
+                                    f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
+                                    f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
                        "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
-            "roofline": {"bound": "mfma", "kernel": "lstm_fwd_kernel<32,12,2,false,false>", "achieved": achieved,
+            "roofline": {"bound": "mfma",
+                         "kernel": "lstm_fwd_big_kernel<128,39,2>" if big else "lstm_fwd_kernel<32,12,2,false,false>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": k_ms, "flop_per_launch": fl},

@@ -187,45 +187,12 @@ __global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ te
 // ============================================================================
 // Persistent LSTM forward
 // ============================================================================
-struct FwdParams {
-    int D, L, C, pool, F;
-    const float* xp;
-    const int32_t* len_sorted;
-    const int32_t* order;
-    const int32_t* tile_T;
-    const int64_t* tile_off;
-    int n_curves, n_tiles, max_T, n_samples;
-    const float* wk;
-    int64_t wk_stride;
-    MaskP mk;
-    // outputs
-    float* out_logits;
-    float* out_probs;
-    int64_t os_s, os_n;
-    // workspace
-    unsigned int* counter;
-    float* yscratch;       // [grid][nbuf][dirs][max_T][H*32]
-    int64_t y_buf_floats;  // dirs*max_T*H*32
-    int nbuf;
-    // training tape (TRAIN kernels only): [n_tiles][tape_tile_floats]
-    float* tape;
-    int64_t tape_tile;
-};
-
 template <int H, int KKI, int DIRS>
 struct PhaseCfg {
     static constexpr int NT = H * 8;                 // threads per workgroup
     static constexpr int ROWS = 2 * KKI;             // input rows staged per step
     static constexpr int NF4 = ROWS * 8;             // float4 per step
     static constexpr int NPT = (NF4 + NT - 1) / NT;  // float4 per thread per step
-};
-
-struct ItemCtx {
-    int tile, s, T, w, lane, cl, hf, tid;
-    int len, orig;          // of this lane's curve
-    const float* wks;       // weight set of this sample
-    float* ybase;           // this workgroup's y scratch
-    float* tape;            // TRAIN: this tile's tape
 };
 
 // One (layer, direction) pass over the tile's T steps.
@@ -597,10 +564,11 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 
 // ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; };
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; };
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs);  // snn_forward_big.hip
 #define FWD_ENTRY(H, K, Dd)                                                                          \
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
-     lstm_fwd_kernel<H, K, Dd, true, true>}
+     lstm_fwd_kernel<H, K, Dd, true, true>, false}
 static const FwdEntry g_fwd[] = {
     FWD_ENTRY(32, 12, 2),  // D = 23..24  (4 filters)
     FWD_ENTRY(32, 13, 2),  // D = 25..26  (4 filters + redshift)
@@ -612,6 +580,12 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
 {
     for (const FwdEntry& e : g_fwd)
         if (e.H == y.H && e.KKI0 == y.KKI[0] && e.dirs == y.dirs) return &e;
+    // hidden sizes whose weights do not fit the register file: two-pass kernel (inference only)
+    static thread_local FwdEntry big;
+    if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs)) {
+        big = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, nullptr, true};
+        return &big;
+    }
     return nullptr;
 }
 extern "C" int snn_supported(const snn_cfg* cfg)
@@ -735,12 +709,14 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 }
 
 // ---- persistent forward launch geometry ------------------------------------
-struct FwdGeom { int grid, nbuf, cus; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
+struct FwdGeom { int grid, nbuf, cus, threads; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
-static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, int max_T, FwdGeom* g)
+static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
-    g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
+    const int threads = big ? 256 : y.H * 8;
+    if (big) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 3 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
+    else g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     static thread_local int cached_dev = -1, cached_cus = 0;
     int dev = 0;
@@ -753,14 +729,17 @@ static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, int max_T, FwdGeom* g)
     }
     int per_cu = 0;
     HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, y.H * 8, g->lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, threads, g->lds));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     g->grid = cached_cus * per_cu;
     g->cus = cached_cus;
     g->nbuf = y.L > 2 ? 2 : 1;
     g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32;
-    g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
+    g->threads = threads;
+    // the two-pass kernel also parks W_ih x_t + b for every step: max_T x 4H x 32 floats per workgroup
+    const int64_t gx = big ? (int64_t)max_T * (y.H / 8) * 1024 : 0;
+    g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * (g->nbuf * g->y_buf_floats + gx);
     return SNN_OK;
 }
 
@@ -773,11 +752,14 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
     FwdGeom g, gt;
-    rc = fwd_geom(y, e->fn, max_T, &g);
-    if (!rc) rc = fwd_geom(y, e->fn_masked, max_T, &gt);
-    if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
-    if (!rc) rc = fwd_geom(y, e->fn_train, max_T, &gt);
-    return rc ? rc : std::max(g.ws_bytes, gt.ws_bytes);
+    rc = fwd_geom(y, e->fn, e->big, max_T, &g);
+    if (!rc && !e->big) {
+        rc = fwd_geom(y, e->fn_masked, false, max_T, &gt);
+        if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+        if (!rc) rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
+        if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+    }
+    return rc ? rc : g.ws_bytes;
 }
 
 int snn_masks_to_device(const snn_masks* masks, int max_T, MaskP* mk)
@@ -834,8 +816,10 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     const bool masked = masks && masks->mode != SNN_MASK_NONE;
     fwd_kernel_t fn = train ? e->fn_train : masked ? e->fn_masked : e->fn;
+    if (!fn) { snn_set_error("training kernels exist for H <= 64 only (H=%d)", y.H); return SNN_ERR_UNSUPPORTED; }
+    if (e->big && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     FwdGeom g;
-    rc = fwd_geom(y, fn, max_T, &g);
+    rc = fwd_geom(y, fn, e->big, max_T, &g);
     if (rc) return rc;
     if (workspace_bytes < g.ws_bytes) {
         snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
@@ -859,7 +843,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
     const int64_t n_items = (int64_t)n_tiles * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(y.H * 8), g.lds, st, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds, st, p);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }

@@ -1,0 +1,361 @@
+// snn_forward_big.hip -- persistent LSTM forward for hidden sizes whose gate weights do not fit the
+// register file next to each other (H = 128: one (layer, dir) is 512 x (I + 128) floats = 0.4-0.8 MB).
+//
+// Same work decomposition as lstm_fwd_kernel (item = (32-curve tile, MC sample), 4 waves, the 32x32 MFMA
+// tile of row-tile tau holds the 4 gates of hidden units 8tau..8tau+7), but one workgroup per CU with the
+// full 512-register budget, each wave owning RT = H/32 row tiles, and the phase split in two passes:
+//   1. input pass (no recurrence): Gx[t] = W_ih x_t + b_ih + b_hh for ALL steps, W_ih row tiles held in
+//      registers TP tiles at a time, results streamed to a per-workgroup scratch slab in C/D register order;
+//   2. recurrent pass: W_hh (RT x H/2 = 256 registers) stays resident, each step starts its RT accumulator
+//      chains from Gx[t] and adds W_hh h_{t-1}; activations, pooling and the head as in the small kernel.
+// Algorithmic FLOPs are unchanged (every weight is used once per curve-step); the extra traffic is the Gx
+// round trip, 4 KB per curve-step-direction (1.2 MFLOP per step at H=128, D=78).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+
+#include "snn_kernels.h"
+#include "snn_host.h"
+
+// One (layer, direction) phase.  TP = row tiles per wave handled by one input pass.
+template <int H, int KKI, int DIRS, bool FIRST, int TP>
+__device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
+                                          int k_head_w, float* xin, float* hb, float* part, float* logit,
+                                          float* mlds, float* gx)
+{
+    constexpr int NT = 256, RT = H / 32, KKH = H / 2, KK = KKI + KKH;
+    constexpr int ROWS = 2 * KKI, NF4 = ROWS * 8, NPT = (NF4 + NT - 1) / NT, XIN_STRIDE = ROWS * 32;
+    constexpr int NWT = H / 8;  // row tiles of the layer
+    static_assert(RT % TP == 0, "tiles per pass must divide the tiles per wave");
+    const FwdParams& y = p;
+    const MaskP& mk = p.mk;
+    const bool masked = mk.mode != SNN_MASK_NONE;
+    const int ld = l * DIRS + d;
+    const bool last_layer = l == y.L - 1;
+    const int T = c.T;
+    const float* Abase = c.wks + k_A;
+    const float* in0 = FIRST ? p.xp + p.tile_off[c.tile] : c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
+    float* yout = last_layer ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+
+    // input-mask registers of the staging threads (layer 0, variational)
+    float min_[NPT][4];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
+    if (FIRST && masked) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                const int k = f >> 3, c4 = (f & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                    if (o >= 0 && k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k);
+                }
+            }
+        }
+    }
+    auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                const float* src;
+                if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
+                else {
+                    const int dd = f / (H * 8), ff = f - dd * (H * 8);
+                    src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
+                }
+                pre[i] = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+    };
+    auto store_step = [&](float* dst, const f32x4 (&pre)[NPT]) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = c.tid + i * NT;
+            if (f < NF4) {
+                f32x4 v = pre[i];
+                if (FIRST) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                }
+                *reinterpret_cast<f32x4*>(dst + f * 4) = v;
+            }
+        }
+    };
+
+    // ================= pass 1: Gx[t][tile][i][lane] = W_ih x_t + b ===================================
+    for (int r0 = 0; r0 < RT; r0 += TP) {
+        float wx[TP][KKI];
+        f32x16 binit[TP];
+#pragma unroll
+        for (int r = 0; r < TP; ++r) {
+            const int tau = c.w * RT + r0 + r;
+            const float* A = Abase + (int64_t)tau * KK * 64 + c.lane;
+#pragma unroll
+            for (int kk = 0; kk < KKI; ++kk) wx[r][kk] = A[kk * 64];
+            const float* B = c.wks + k_bias + (tau * 2 + c.hf) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) binit[r][i] = B[i] + B[NWT * 32 + i];
+        }
+        {
+            f32x4 pre[NPT];
+            load_step(0, pre);
+            store_step(xin, pre);
+        }
+        lds_barrier();
+        for (int t = 0; t < T; ++t) {
+            const int cur = t & 1;
+            f32x4 pre[NPT];
+            const bool more = t + 1 < T;
+            if (more) load_step(t + 1, pre);
+            f32x16 acc[TP];
+#pragma unroll
+            for (int r = 0; r < TP; ++r) acc[r] = binit[r];
+            const float* xc = xin + cur * XIN_STRIDE + c.lane;
+#pragma unroll
+            for (int kk = 0; kk < KKI; ++kk) {
+                const float b = xc[kk * 64];
+#pragma unroll
+                for (int r = 0; r < TP; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[r][kk], b, acc[r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < TP; ++r) {
+                float* g = gx + ((int64_t)t * NWT + (c.w * RT + r0 + r)) * 1024 + c.lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) g[i * 64] = acc[r][i];
+            }
+            if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre);
+            lds_barrier();
+        }
+    }
+    __syncthreads();  // Gx visible to the whole workgroup (each wave reads its own tiles, but keep it simple)
+
+    // ================= pass 2: recurrence ==========================================================
+    float wh[RT][KKH];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int tau = c.w * RT + r;
+        const float* A = Abase + ((int64_t)tau * KK + KKI) * 64 + c.lane;
+#pragma unroll
+        for (int kk = 0; kk < KKH; ++kk) wh[r][kk] = A[kk * 64];
+        if (d == 0 && masked) {  // variational W_hh row mask (forward direction only)
+            const int rr = c.lane & 31;
+            const float m = mask_whh(mk, c.s, y.L, H, l, (rr >> 3) * H + 8 * tau + (rr & 7));
+#pragma unroll
+            for (int kk = 0; kk < KKH; ++kk) wh[r][kk] = __fmul_rn(m, wh[r][kk]);
+        }
+    }
+    // locked between-layer mask of this lane's units, parked in LDS: mlds[unit][curve]
+    const bool use_mid = masked && !last_layer;
+    if (use_mid) {
+        for (int idx = c.tid; idx < H * 32; idx += NT) {
+            const int j = idx >> 5, cc = idx & 31;
+            const int o = p.order[c.tile * SNN_TILE + cc];
+            mlds[idx] = o >= 0 ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, o, d * H + j) : 1.0f;
+        }
+    }
+    float cst[RT][4], hst[RT][4], hsum[RT][4];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cst[r][u] = hst[r][u] = hsum[r][u] = 0.0f;
+            hb[(8 * (c.w * RT + r) + 4 * c.hf + u) * 32 + c.cl] = 0.0f;
+        }
+    f32x16 acc[RT];
+    {
+        const int t0 = d == 0 ? 0 : T - 1;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float* g = gx + ((int64_t)t0 * NWT + (c.w * RT + r)) * 1024 + c.lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
+        }
+    }
+    lds_barrier();
+    for (int step = 0; step < T; ++step) {
+        const int t = d == 0 ? step : T - 1 - step;
+        const int tn = d == 0 ? t + 1 : t - 1;
+        const int cur = step & 1;
+        const bool more = step + 1 < T;
+        const float* hc = hb + cur * (H * 32) + c.lane;
+#pragma unroll
+        for (int kk = 0; kk < KKH; ++kk) {
+            const float b = hc[kk * 64];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
+        }
+        const bool valid = t < c.len;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
+            float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
+            float outv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float ig = snn_sigmoid(acc[r][u]);
+                const float fg = snn_sigmoid(acc[r][4 + u]);
+                const float gg = snn_tanh(acc[r][8 + u]);
+                const float og = snn_sigmoid(acc[r][12 + u]);
+                const float cn = fmaf(fg, cst[r][u], __fmul_rn(ig, gg));
+                const float hv = og * snn_tanh(cn);
+                cst[r][u] = valid ? cn : cst[r][u];
+                hst[r][u] = valid ? hv : hst[r][u];
+                outv[u] = valid ? hv : 0.0f;
+                hn[u * 32] = hst[r][u];
+            }
+            // the next step's Gx for this tile goes straight into the now-free accumulator
+            if (more) {
+                const float* g = gx + ((int64_t)tn * NWT + (c.w * RT + r)) * 1024 + c.lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
+            }
+            if (last_layer) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hsum[r][u] += outv[u];
+            } else {
+                float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    yo[u * 32] = use_mid ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[u]) : outv[u];
+            }
+        }
+        lds_barrier();
+    }
+
+    // ---- head contribution of this phase
+    const bool contributes = y.pool == SNN_POOL_STANDARD || last_layer;
+    if (contributes) {
+        const float* Wo = c.wks + k_head_w;
+        for (int q = 0; q < y.C; ++q) {
+            float a = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float feat;
+                    int fidx;
+                    if (y.pool == SNN_POOL_MEAN) {
+                        feat = __fdiv_rn(hsum[r][u], (float)(c.len > 0 ? c.len : 1));
+                        fidx = d * H + j0 + u;
+                    } else {
+                        feat = hst[r][u];
+                        fidx = (j0 + u) * (y.L * DIRS) + ld;
+                    }
+                    if (masked && c.orig >= 0) feat = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, c.orig, fidx), feat);
+                    a = fmaf(Wo[q * y.F + fidx], feat, a);
+                }
+            }
+            a += __shfl_xor(a, 32);
+            if (c.hf == 0) part[(c.w * y.C + q) * 32 + c.cl] = a;
+        }
+        __syncthreads();
+        for (int idx = c.tid; idx < y.C * 32; idx += NT) {
+            const int q = idx >> 5, cc = idx & 31;
+            float a = logit[idx];
+            for (int w = 0; w < 4; ++w) a += part[(w * y.C + q) * 32 + cc];
+            logit[idx] = a;
+        }
+    }
+    __syncthreads();
+}
+
+template <int H, int KKI0, int DIRS>
+__global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
+{
+    constexpr int NT = 256;
+    constexpr int KKI1 = DIRS * H / 2;
+    constexpr int ROWS = (2 * KKI0 > 2 * KKI1) ? 2 * KKI0 : 2 * KKI1;
+    constexpr int NWT = H / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdParams& y = p;
+    constexpr int BLK0 = NWT * (KKI0 + H / 2) * 64 + 2 * NWT * 32;
+    constexpr int BLK1 = NWT * (KKI1 + H / 2) * 64 + 2 * NWT * 32;
+    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
+    float* xin = smem;                     // [2][ROWS*32]
+    float* hb = xin + 2 * ROWS * 32;       // [2][H*32]
+    float* mlds = hb + 2 * H * 32;         // [H*32]
+    float* part = mlds + H * 32;           // [4][C][32]
+    float* logit = part + 4 * y.C * 32;    // [C][32]
+    int* item_slot = reinterpret_cast<int*>(logit + y.C * 32);
+
+    ItemCtx c;
+    c.tid = threadIdx.x;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.cl = c.lane & 31;
+    c.hf = c.lane >> 5;
+    c.tape = nullptr;
+    // per-workgroup scratch: [nbuf y buffers][Gx: max_T * NWT * 1024]
+    const int64_t gx_floats = (int64_t)p.max_T * NWT * 1024;
+    float* wg = p.yscratch + (int64_t)blockIdx.x * (p.nbuf * p.y_buf_floats + gx_floats);
+    c.ybase = wg;
+    float* gx = wg + p.nbuf * p.y_buf_floats;
+    const int64_t n_items = (int64_t)p.n_tiles * p.n_samples;
+
+    for (;;) {
+        if (c.tid == 0) *item_slot = (int)atomicAdd(p.counter, 1u);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(*item_slot);
+        if (item >= n_items) break;
+        c.tile = item / p.n_samples;
+        c.s = item - c.tile * p.n_samples;
+        c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+        const int pos = c.tile * SNN_TILE + c.cl;
+        c.len = p.len_sorted[pos];
+        c.orig = p.order[pos];
+        c.wks = p.wk + (int64_t)c.s * p.wk_stride;
+        for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
+        __syncthreads();
+
+        for (int l = 0; l < y.L; ++l) {
+            for (int d = 0; d < DIRS; ++d) {
+                if (l == 0) {
+                    const int kA = d * BLK0;
+                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 1)>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
+                                                                            k_head_w, xin, hb, part, logit, mlds, gx);
+                } else {
+                    const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
+                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 1)>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
+                                                                             k_head_w, xin, hb, part, logit, mlds, gx);
+                }
+            }
+        }
+        if (c.tid < 32) {
+            const int orig = c.orig;
+            if (orig >= 0) {
+                const float* bo = c.wks + k_head_w + y.C * y.F;
+                float mx = -INFINITY;
+                for (int q = 0; q < y.C; ++q) mx = fmaxf(mx, logit[q * 32 + c.tid] + bo[q]);
+                float z = 0.0f;
+                for (int q = 0; q < y.C; ++q) z += expf(logit[q * 32 + c.tid] + bo[q] - mx);
+                const int64_t o = (int64_t)c.s * p.os_s + (int64_t)orig * p.os_n;
+                for (int q = 0; q < y.C; ++q) {
+                    const float lg = logit[q * 32 + c.tid] + bo[q];
+                    if (p.out_logits) p.out_logits[o + q] = lg;
+                    if (p.out_probs) p.out_probs[o + q] = __fdiv_rn(expf(lg - mx), z);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- registry hooks used by snn_forward.hip -------------------------------------------------------
+typedef void (*fwd_kernel_t)(const FwdParams);
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs)
+{
+    if (H == 128 && dirs == 2) {
+        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 2>;   // D = 75..76 (6 filters)
+        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 2>;   // D = 77..78 (6 filters + redshift)
+        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 2>;   // D = 23..24
+        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 2>;   // D = 25..26
+    }
+    return nullptr;
+}

@@ -77,5 +77,39 @@ __host__ __device__ inline int64_t tape_tile_floats(int H, int n_ld, int max_T, 
     return (int64_t)n_ld * max_T * tape_step_floats(H) + (int64_t)F * 32;
 }
 
+// ---- forward kernel parameters (snn_forward.hip, snn_forward_big.hip) ---------
+struct FwdParams {
+    int D, L, C, pool, F;
+    const float* xp;
+    const int32_t* len_sorted;
+    const int32_t* order;
+    const int32_t* tile_T;
+    const int64_t* tile_off;
+    int n_curves, n_tiles, max_T, n_samples;
+    const float* wk;
+    int64_t wk_stride;
+    MaskP mk;
+    // outputs
+    float* out_logits;
+    float* out_probs;
+    int64_t os_s, os_n;
+    // workspace
+    unsigned int* counter;
+    float* yscratch;       // [grid][nbuf][dirs][max_T][H*32]
+    int64_t y_buf_floats;  // dirs*max_T*H*32
+    int nbuf;
+    // training tape (TRAIN kernels only): [n_tiles][tape_tile_floats]
+    float* tape;
+    int64_t tape_tile;
+};
+
+struct ItemCtx {
+    int tile, s, T, w, lane, cl, hf, tid;
+    int len, orig;          // of this lane's curve
+    const float* wks;       // weight set of this sample
+    float* ybase;           // this workgroup's y scratch
+    float* tape;            // TRAIN: this tile's tape
+};
+
 // host-side mask validation / conversion (snn_forward.hip)
 int snn_masks_to_device(const snn_masks* masks, int max_T, MaskP* out);

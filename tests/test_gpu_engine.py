@@ -75,7 +75,7 @@ def test_variational_golden(tag, D, C, pool):
 
 
 @pytest.mark.parametrize("tag,D,H,C,pool", [("mean", 24, 32, 2, "mean"), ("standard", 26, 32, 3, "standard"),
-                                            ("h64", 24, 64, 5, "mean")])
+                                            ("h64", 24, 64, 5, "mean"), ("h128_d78", 78, 128, 14, "mean")])
 def test_bayesian_golden(tag, D, H, C, pool):
     E = _eng()
     g = load_golden(f"g3_bayesian_{tag}")
@@ -183,3 +183,29 @@ def test_large_batch_properties():
         w, _ = oracle.bbb_sample(mu[:cfg.P - C], rho, eps[s])
         o = oracle.forward(ocfg, np.ascontiguousarray(x[:, sub]), lengths[sub], np.concatenate([w, mu[cfg.P - C:]]))
         _check(lo[s][sub], pr[s][sub], o["logits"], o["probs"])
+
+
+@pytest.mark.parametrize("D,C,pool,N,T", [(78, 14, "mean", 70, 300), (76, 20, "standard", 33, 25), (24, 2, "mean", 40, 40)])
+def test_h128_two_pass_kernel_vs_oracle(D, C, pool, N, T):
+    """Config 5 shape (hidden 128, 6 filters + redshift, multi-class, 300-step sequences) on the two-pass
+    kernel, with variational masks, vs the C oracle."""
+    E = _eng()
+    H, L, S = 128, 2, 2
+    cfg = E.Config(D, H, L, True, C, pool)
+    assert cfg.supported()
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    g = np.random.default_rng(21)
+    w = _random_model(cfg, 22, 0.08)
+    x, lengths = make_curves(23, N, T, D, min_len=max(1, T // 3))
+    p = 0.1
+    bern = lambda *s: (g.random(s) < 1 - p).astype(np.float32) / np.float32(1 - p)
+    m_in, m_whh, m_mid, m_out = bern(S, N, D), bern(S, L, 4 * H), bern(S, L - 1, 1, N, 2 * H), bern(S, N, cfg.F)
+    masks = E.Masks(mode=1, m_in=_t(m_in), m_whh=_t(m_whh), m_mid=_t(m_mid), m_out=_t(m_out), mid_T=1)
+    wk = E.prepare_weights(cfg, _t(w))
+    lo, pr = _run(E, cfg, x, lengths, wk, S, masks)
+    for s in range(S):
+        o = oracle.forward(ocfg, x, lengths, w, m_in[s], m_whh[s], m_mid[s], m_out[s])
+        _check(lo[s], pr[s], o["logits"], o["probs"])
+    lo, pr = _run(E, cfg, x, lengths, wk, 1)
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])

@@ -42,7 +42,8 @@ def test_sizes_and_errors_through_abi():
     assert cfg.P == 40066 and cfg.F == 64          # 40 066 params at H=32, D=24, C=2
     assert cfg.PK >= cfg.P and cfg.supported()
     assert E.Config(26, 32, 2, True, 3, "standard").F == 128
-    assert not E.Config(78, 128, 2, True, 14, "mean").supported()
+    assert E.Config(78, 128, 2, True, 14, "mean").supported()      # two-pass kernel (config 5)
+    assert not E.Config(50, 128, 2, True, 14, "mean").supported()
     with pytest.raises(_lib.SnnError):
         E.Config(24, 30, 2, True, 2, "mean").P     # H % 8 != 0
     with pytest.raises(_lib.SnnError):
