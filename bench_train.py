@@ -1,0 +1,128 @@
+#!/usr/bin/env python
+"""bench_train.py -- secondary benchmark (BASELINE configs[3]): BayesianRNN training step
+(forward-train + CE + BPTT + BBB/KL backward + fused Adam), data-parallel over RCCL.
+
+  python bench_train.py [--batch 128] [--steps 50] [--warmup 10] [--path fused|autograd]
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... bench_train.py --gpus N
+
+Weak scaling: every rank trains on `--batch` curves per step (global batch = N x batch); one all-reduce of
+the flat fp32 gradient (320 KB) per step.  Prints one JSON line (rank 0).  bench.py remains the driver's
+contract benchmark (inference metric of BASELINE.json)."""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pack_padded_sequence
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def settings(**kw):
+    d = dict(model="bayesian", layer_type="lstm", nb_classes=2, hidden_dim=32, num_layers=2, dropout=0.05,
+             bidirectional=True, use_cuda=True, rnn_output_option="mean", pi=0.75, log_sigma1=-1.0,
+             log_sigma2=-7.0, rho_scale_lower=4.0, rho_scale_upper=3.0, log_sigma1_output=-1.0,
+             log_sigma2_output=-7.0, rho_scale_lower_output=4.0, rho_scale_upper_output=3.0,
+             random_length=False, random_redshift=False, redshift="none", no_dump=True,
+             learning_rate=1e-3, weight_decay=0.0)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="curves per GPU per step")
+    ap.add_argument("--model", default="bayesian", choices=["bayesian", "variational", "vanilla"])
+    ap.add_argument("--path", default="fused", choices=["fused", "autograd"])
+    ap.add_argument("--cpu-steps", type=int, default=20, help="train steps of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from supernnova_amd import distributed as D
+    from supernnova_amd.utils import training_utils as tu
+    D.init_from_env("nccl", dev)
+
+    st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0)
+    torch.manual_seed(0)                       # identical init and identical Philox seeds on every rank
+    rnn = tu.get_model(st, 24).to(dev)
+    D.broadcast_parameters(rnn)
+    rnn.dp_curve_base = rank * args.batch
+    opt = tu.get_optimizer(st, rnn)
+    g = np.random.default_rng(100 + rank)
+    B, T = args.batch, 40
+    lengths = np.sort(g.integers(3, T + 1, size=B))[::-1].copy()
+    x = g.standard_normal((int(lengths[0]), B, 24)).astype(np.float32)
+    for b in range(B):
+        x[lengths[b]:, b] = 0
+    packed = pack_padded_sequence(torch.from_numpy(x).to(dev), torch.from_numpy(lengths.astype(np.int64)))
+    target = torch.from_numpy(g.integers(0, 2, size=B)).to(dev)
+    crit = torch.nn.CrossEntropyLoss()
+    nb, gB = 100, B * world
+
+    def step():
+        if args.path == "fused":
+            return tu.train_step_fused(st, rnn, packed, target, opt, gB, nb)
+        return tu.train_step(st, rnn, packed, target, crit, opt, gB, nb)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(loss))
+    if rank == 0:
+        out = {"metric": f"light curves/s trained, {args.model} RNN (fwd + ELBO/KL bwd + Adam), data-parallel",
+               "value": gB * args.steps / dt, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.model} LSTM 32x2 bidirectional D=24 C=2, batch {B} per GPU, lengths U{{3..40}}, "
+                                      f"path={args.path}", "global_batch": gB, "parallelism": f"dp{world}"}}
+        if args.cpu_steps > 0 and world == 1:
+            from oracle import torch_port as tp
+            sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rnn.state_dict().items()}
+            pk = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths.astype(np.int64)))
+            tg = target.cpu()
+            copt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                copt.zero_grad()
+                l, _ = tp.train_loss(args.model, sd, pk, tg, B, nb)
+                l.backward()
+                copt.step()
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": B * args.cpu_steps / cdt, "unit": "light curves/s",
+                                   "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"{args.cpu_steps} train steps of the same batch on the stock-PyTorch port"}
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

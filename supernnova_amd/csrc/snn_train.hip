@@ -131,7 +131,8 @@ __device__ __forceinline__ void bwd_phase(const BwdParams& p, float* smem, int t
 
     const float* tape_ld = tape + (int64_t)ld * p.max_T * tape_step_floats(H);
     const float* xtile = p.xp + p.tile_off[tile];
-    float* dy_in = last_layer ? nullptr : dybuf_in + (int64_t)d * p.max_T * H * 32;
+    const int64_t dy_src = (int64_t)DIRS * p.max_T * H * 32;   // floats of one producing direction's dy block
+    const float* dy_in = last_layer ? nullptr : dybuf_in + (int64_t)d * p.max_T * H * 32;
 
     // staging of [h_prev | x_t] for processing step `step` into buffer `buf` (transposed-read image, stride 33)
     auto stage_load = [&](int step, f32x4 (&pre)[NPT]) {
@@ -194,6 +195,29 @@ __device__ __forceinline__ void bwd_phase(const BwdParams& p, float* smem, int t
     __syncthreads();
 
     const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+    // tape values of one step for this lane's 4 units: i, f, g, o, c (5 x 4) and the gradient arriving from
+    // the layer above (both of its directions); loaded one step ahead so the L2/HBM latency hides behind the
+    // MFMAs of the running step (the barriers inside the loop are LDS-only and do not drain vector memory)
+    struct StepVals { float q[5][4]; float dy[4]; };
+    auto load_vals = [&](int step, StepVals& v) {
+        const int t = d == 0 ? step : T - 1 - step;
+        const float* tq = tape_ld + (int64_t)t * tape_step_floats(H) + j0 * 32 + cl;
+#pragma unroll
+        for (int g = 0; g < 5; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v.q[g][u] = tq[(g * H + u) * 32];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v.dy[u] = 0.0f;
+            if (!last_layer) {
+                const int64_t o = (int64_t)t * H * 32 + (j0 + u) * 32 + cl;
+                v.dy[u] = dy_in[o];
+                if (DIRS == 2) v.dy[u] += dy_in[dy_src + o];
+            }
+        }
+    };
+    StepVals curv, nxtv;
+    load_vals(T - 1, curv);
     for (int sb = 0; sb < T; ++sb) {
         const int step = T - 1 - sb;
         const int t = d == 0 ? step : T - 1 - step;
@@ -202,36 +226,30 @@ __device__ __forceinline__ void bwd_phase(const BwdParams& p, float* smem, int t
         const bool valid = t < len;
         const bool prev_live = step > 0 && tp < len;
         f32x4 pre[NPT];
-        if (step > 0) stage_load(step - 1, pre);
+        if (step > 0) {
+            load_vals(step - 1, nxtv);
+            stage_load(step - 1, pre);
+        }
 
         // ---- dgates of this lane's 4 units (C/D register order i = gate*4 + u)
         float dga[16];
-        {
-            const float* tq = tape_ld + (int64_t)t * tape_step_floats(H) + j0 * 32 + cl;
-            const float* tqp = tape_ld + (int64_t)tp * tape_step_floats(H) + 4 * H * 32 + j0 * 32 + cl;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float dh = dhrec[(j0 + u) * 32 + cl];
-                if (last_layer) {
-                    if (y.pool == SNN_POOL_MEAN && valid) dh += dfeat[(d * H + j0 + u) * 32 + cl] * inv_len;
-                } else {
-                    dh += dy_in[(int64_t)t * H * 32 + (j0 + u) * 32 + cl];
-                }
-                float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
-                if (valid) {
-                    const float ig = tq[(0 * H + u) * 32], fg = tq[(1 * H + u) * 32], gg = tq[(2 * H + u) * 32];
-                    const float og = tq[(3 * H + u) * 32], cn = tq[(4 * H + u) * 32];
-                    const float cp = prev_live ? tqp[u * 32] : 0.0f;
-                    const float tc = snn_tanh(cn);
-                    const float dct = dc[u] + dh * og * (1.0f - tc * tc);
-                    dao = dh * tc * og * (1.0f - og);
-                    dai = dct * gg * ig * (1.0f - ig);
-                    daf = dct * cp * fg * (1.0f - fg);
-                    dag = dct * ig * (1.0f - gg * gg);
-                    dc[u] = dct * fg;
-                }
-                dga[0 + u] = dai; dga[4 + u] = daf; dga[8 + u] = dag; dga[12 + u] = dao;
+        for (int u = 0; u < 4; ++u) {
+            float dh = dhrec[(j0 + u) * 32 + cl] + curv.dy[u];
+            if (last_layer && y.pool == SNN_POOL_MEAN && valid) dh += dfeat[(d * H + j0 + u) * 32 + cl] * inv_len;
+            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+            if (valid) {
+                const float ig = curv.q[0][u], fg = curv.q[1][u], gg = curv.q[2][u], og = curv.q[3][u], cn = curv.q[4][u];
+                const float cp = prev_live ? nxtv.q[4][u] : 0.0f;   // c of the previous processed step
+                const float tc = snn_tanh(cn);
+                const float dct = dc[u] + dh * og * (1.0f - tc * tc);
+                dao = dh * tc * og * (1.0f - og);
+                dai = dct * gg * ig * (1.0f - ig);
+                daf = dct * cp * fg * (1.0f - fg);
+                dag = dct * ig * (1.0f - gg * gg);
+                dc[u] = dct * fg;
             }
+            dga[0 + u] = dai; dga[4 + u] = daf; dga[8 + u] = dag; dga[12 + u] = dao;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -250,7 +268,7 @@ __device__ __forceinline__ void bwd_phase(const BwdParams& p, float* smem, int t
 #pragma unroll
             for (int i = 0; i < 16; ++i) r[((i & 3) + 8 * (i >> 2) + 4 * hf) * 32] = acc[i];
         }
-        __syncthreads();  // A: dG and red complete
+        lds_barrier();  // A: dG and red complete
 
         // ---- dW^T += [h_prev | x_t] (KR x 32 curves) . dgates^T (32 curves x this wave's 32 gate rows)
         {
@@ -280,13 +298,14 @@ __device__ __forceinline__ void bwd_phase(const BwdParams& p, float* smem, int t
                 if (f < DIRS * H) {
                     if (masked && origs[c] >= 0) s = __fmul_rn(mask_mid(mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, origs[c], f), s);
                     const int dd = f / H, jj = f - dd * H;
-                    float* o = dybuf_out + ((int64_t)dd * p.max_T + t) * H * 32 + jj * 32 + c;
-                    *o = d == 0 ? s : *o + s;
+                    // one buffer per producing direction (summed by the consumer): no read-modify-write
+                    dybuf_out[(int64_t)d * dy_src + ((int64_t)dd * p.max_T + t) * H * 32 + jj * 32 + c] = s;
                 }
             }
         }
         if (step > 0) stage_store(xh + (cur ^ 1) * LD::KROWS * LDS_PAD, pre);
-        __syncthreads();  // B
+        curv = nxtv;
+        lds_barrier();  // B
     }
 
     // ---- write-out into this workgroup's private slab (canonical layout)
@@ -333,8 +352,8 @@ __global__ void __launch_bounds__(H * 8) lstm_bwd_kernel(const BwdParams p)
     float* dlg = smem + LD::FIXED;        // [C][32]
     float* dfeat = dlg + y.C * 32;        // [F][32]
     float* slab = p.slabs + (int64_t)blockIdx.x * y.P;
-    float* dyb = p.dyscratch + (int64_t)blockIdx.x * 2 * DIRS * p.max_T * H * 32;
-    const int64_t dy_buf = (int64_t)DIRS * p.max_T * H * 32;
+    const int64_t dy_buf = (int64_t)DIRS * DIRS * p.max_T * H * 32;   // [producer dir][dir][max_T][H*32]
+    float* dyb = p.dyscratch + (int64_t)blockIdx.x * 2 * dy_buf;
     const float* Wo = p.wk + y.k_head_w;
 
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
@@ -423,7 +442,7 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     if (rc) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
     const int grid = std::min(n_tiles, BWD_MAX_GRID);
-    return (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * max_T * y.H * 32);
+    return (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * y.dirs * max_T * y.H * 32);
 }
 
 extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted, const int32_t* order,
@@ -448,7 +467,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (tape_floats < tape_tile * n_tiles) { snn_set_error("snn_lstm_backward: tape too small"); return SNN_ERR_ARG; }
     const int grid = std::min(n_tiles, BWD_MAX_GRID);
-    const int64_t need = (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * max_T * y.H * 32);
+    const int64_t need = (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * y.dirs * max_T * y.H * 32);
     if (workspace_bytes < need) {
         snn_set_error("snn_lstm_backward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)need);
         return SNN_ERR_WORKSPACE;
