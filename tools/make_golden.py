@@ -469,11 +469,119 @@ def g5_mc_stats():
              n_ref=np.int64(n_ref), S=np.int64(S), dropout=np.float32(st.dropout))
 
 
+# ---------------------------------------------------------------- G7 on-the-fly (broker) path
+def _grab(path, names, ns):
+    """exec the named top-level functions of a reference file (its module imports h5py/astropy/colorama,
+    which this image lacks, so the module as a whole cannot be imported)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+
+
+def onthefly_frames():
+    """(name, DataFrame) inputs: the reference's example light curve as run_onthefly.load_lc_csv reads it
+    (:41-84: sorted by MJD, SNID int -> str), and a synthetic multi-curve alert batch with the awkward cases
+    (unsorted rows, repeated filters inside one 8-hour group, equal MJDs, a filter the model does not know,
+    string SNIDs whose lexicographic order differs from the numeric one, a 1-row curve)."""
+    import pandas as pd
+    df = pd.read_csv("/root/reference/tests/onthefly_lc/example_lc.csv")
+    df = df.sort_values(by=["MJD"])
+    df["SNID"] = df["SNID"].astype(int).astype(str)
+    frames = [("example", df[["SNID", "MJD", "FLUXCAL", "FLUXCALERR", "FLT"]].reset_index(drop=True))]
+    g = np.random.default_rng(77)
+    rows = []
+    for snid, n in (("9", 25), ("10", 40), ("123", 7), ("7", 1), ("88", 60), ("1000", 33)):
+        t = 57000.0 + np.cumsum(g.choice([0.0, 0.01, 0.1, 0.2, 0.34, 0.5, 1.0, 3.0, 7.5], size=n))
+        for k in range(n):
+            rows.append((snid, t[k], g.normal(50, 200), abs(g.normal(10, 5)) + 0.1,
+                         g.choice(["g", "r", "i", "z", "Y"], p=[0.25, 0.25, 0.2, 0.2, 0.1])))
+    rows.append(("88", 57000.0 - 5.0, -3000.0, 4.0, "g"))       # below the training minimum: clipped
+    df2 = pd.DataFrame(rows, columns=["SNID", "MJD", "FLUXCAL", "FLUXCALERR", "FLT"])
+    df2 = df2.iloc[g.permutation(len(df2))].reset_index(drop=True)
+    frames.append(("synthetic", df2))
+    return frames
+
+
+def g7_onthefly():
+    """validate_onthefly.classify_lcs (:123-236) on the bundled vanilla model.  format_data (:65-120),
+    data_utils.compute_delta_time (:364-390), make_dataset.pivot_dataframe_single_from_df (:800-938),
+    training_utils.normalize_arr (:23-86) and conf.get_norm_from_model (:722-738) are the reference's own
+    code, exec'd from its files; the glue between them (:160-188 and get_data_batch's sort/pad/pack) is
+    re-stated here because classify_lcs itself needs ExperimentSettings/h5py.  NOTE: with pandas >= 2
+    get_dummies returns bool columns, `sel.values` becomes an object array and the reference's np.log raises
+    TypeError (seen here with pandas 2.3.3 / numpy 2.2); the one-hot columns are cast to float32 -- the dtype
+    the same code yields with uint8 dummies -- before `.values`."""
+    import json
+    from pathlib import Path
+    import pandas as pd
+    R = "/root/reference/python/supernnova"
+    du = {"np": np, "pd": pd, "os": os}
+    _grab(f"{R}/utils/data_utils.py", {"compute_delta_time", "load_fitfile"}, du)
+    data_utils = SimpleNamespace(compute_delta_time=du["compute_delta_time"], load_fitfile=du["load_fitfile"])
+    md = {"np": np, "pd": pd, "data_utils": data_utils}
+    _grab(f"{R}/data/make_dataset.py", {"pivot_dataframe_single_from_df"}, md)
+    tun = {"np": np}
+    _grab(f"{R}/utils/training_utils.py", {"normalize_arr"}, tun)
+    cf = {"Path": Path}
+    _grab(f"{R}/conf.py", {"get_norm_from_model"}, cf)
+    vo = {"np": np, "pd": pd, "data_utils": data_utils,
+          "pivot_dataframe_single_from_df": md["pivot_dataframe_single_from_df"]}
+    _grab(f"{R}/validation/validate_onthefly.py", {"format_data"}, vo)
+    mdir = "/root/reference/tests/onthefly_model"
+    mf = f"{mdir}/vanilla_S_0_CLF_2_R_none_photometry_DF_1.0_N_global_lstm_32x2_0.05_128_True_mean.pt"
+    cli = json.load(open(f"{mdir}/cli_args.json"))
+    cli.setdefault("sntype_var", "SNTYPE")
+    cli.setdefault("additional_train_var", None)
+    st = cf["get_norm_from_model"](mf, SimpleNamespace(**cli))
+    st.idx_features_to_normalize = [i for i, f in enumerate(st.training_features)
+                                    if f in st.training_features_to_normalize]
+    st.idx_features = [i for i, f in enumerate(st.all_features) if f in st.training_features]
+    rnn = build(vanilla_rnn.VanillaRNN, len(st.training_features), st)
+    rnn.load_state_dict(torch.load(mf, map_location="cpu", weights_only=True))
+    rnn.eval()
+    out = {}
+    import warnings
+    for name, df in onthefly_frames():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fd = vo["format_data"](df.copy(), st)
+        fd = fd.astype({c: np.float32 for c in fd.columns if fd[c].dtype == bool})
+        ids, list_lcs = [], []
+        for snid, sel in fd.groupby(level=0):
+            X_all = sel.values
+            assert X_all.dtype == np.float32
+            X_clip = np.clip(X_all.copy()[:, st.idx_features_to_normalize], st.arr_norm[:, 0], np.inf)
+            X_all[:, st.idx_features_to_normalize] = X_clip
+            X_normed = tun["normalize_arr"](X_all.copy(), st)[:, st.idx_features]
+            ids.append(snid)
+            list_lcs.append(X_normed)
+        lens = np.array([len(x) for x in list_lcs])
+        idx_sort = np.argsort(lens)[::-1]
+        T, B, D = lens.max(), len(lens), list_lcs[0].shape[1]
+        X = np.zeros((T, B, D), np.float32)
+        for j, k in enumerate(idx_sort):
+            X[: lens[k], j] = list_lcs[k]
+        packed = pack_padded_sequence(torch.from_numpy(X), lens[idx_sort].tolist())
+        with torch.no_grad():
+            probs = softmax(rnn(packed))[np.argsort(idx_sort)]
+        assert list(fd.index.unique()) == ids
+        out[name] = dict(snid=np.array(df["SNID"].values, dtype="U8"), mjd=df["MJD"].values.astype(np.float64),
+                         flux=df["FLUXCAL"].values.astype(np.float64), err=df["FLUXCALERR"].values.astype(np.float64),
+                         flt=np.array(df["FLT"].values, dtype="U2"),
+                         fmt_index=np.array(fd.index.values, dtype="U8"), fmt_values=fd.values.astype(np.float32),
+                         ids=np.array(ids, dtype="U8"), lengths=lens.astype(np.int64),
+                         x_normed=np.concatenate(list_lcs, 0).astype(np.float32), probs=probs[:, None, :])
+        print(f"  g7 {name}: {B} curves, rows {lens.tolist()}, probs[0] {probs[0]}")
+    save("g7_onthefly", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7"]
     if "g0" in which:
         g0_init()
     if "g1" in which:
@@ -486,3 +594,5 @@ if __name__ == "__main__":
         g4_train()
     if "g5" in which:
         g5_mc_stats()
+    if "g7" in which:
+        g7_onthefly()
