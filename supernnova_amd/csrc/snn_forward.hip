@@ -380,6 +380,10 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) hsum[u] += outv[u];
         } else if (!TRAIN) {
+#ifdef SNN_ABL_NOYST   // timing ablation only: no layer-output stores
+            if (p.n_curves < 0)
+#endif
+            {
             float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
             if (mid_step && c.orig >= 0) {
 #pragma unroll
@@ -388,6 +392,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mmid[u], outv[u]);
+            }
             }
         }
         if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
@@ -565,7 +570,8 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 // ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; };
-fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs);  // snn_forward_big.hip
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs);   // snn_forward_big.hip
+fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);  // snn_forward_pair.hip
 #define FWD_ENTRY(H, K, Dd)                                                                          \
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
      lstm_fwd_kernel<H, K, Dd, true, true>, false}
@@ -711,11 +717,12 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 // ---- persistent forward launch geometry ------------------------------------
 struct FwdGeom { int grid, nbuf, cus, threads; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
-static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g)
+static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g, bool pair = false)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
     const int threads = big ? 256 : y.H * 8;
     if (big) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 3 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
+    else if (pair) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)2 * (y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     else g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     static thread_local int cached_dev = -1, cached_cus = 0;
@@ -735,7 +742,7 @@ static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, Fw
     g->grid = cached_cus * per_cu;
     g->cus = cached_cus;
     g->nbuf = y.L > 2 ? 2 : 1;
-    g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32;
+    g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32 * (pair ? 2 : 1);
     g->threads = threads;
     // the two-pass kernel also parks W_ih x_t + b for every step: max_T x 4H x 32 floats per workgroup
     const int64_t gx = big ? (int64_t)max_T * (y.H / 8) * 1024 : 0;
@@ -758,6 +765,10 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
         if (!rc) rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+        if (fwd_kernel_t fp = rc ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs)) {
+            rc = fwd_geom(y, fp, false, max_T, &gt, true);
+            if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+        }
     }
     return rc ? rc : g.ws_bytes;
 }
@@ -818,8 +829,15 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     fwd_kernel_t fn = train ? e->fn_train : masked ? e->fn_masked : e->fn;
     if (!fn) { snn_set_error("training kernels exist for H <= 64 only (H=%d)", y.H); return SNN_ERR_UNSUPPORTED; }
     if (e->big && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
+    // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)
+    bool pair = false;
+    if (!train && !masked && !e->big && n_tiles > 1) {
+        static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
+        fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs);
+        if (fp) { fn = fp; pair = true; }
+    }
     FwdGeom g;
-    rc = fwd_geom(y, fn, e->big, max_T, &g);
+    rc = fwd_geom(y, fn, e->big, max_T, &g, pair);
     if (rc) return rc;
     if (workspace_bytes < g.ws_bytes) {
         snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
@@ -841,7 +859,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     p.tape = tape; p.tape_tile = tape_tile;
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
-    const int64_t n_items = (int64_t)n_tiles * n_samples;
+    const int64_t n_items = (int64_t)(pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds, st, p);
     HIP_CHECK(hipGetLastError());

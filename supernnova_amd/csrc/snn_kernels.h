@@ -63,7 +63,11 @@ __device__ __forceinline__ float mask_out(const MaskP& m, int s, int n_curves, i
 // read after a later __syncthreads()).
 __device__ __forceinline__ void lds_barrier()
 {
+#ifdef SNN_ABL_NOBAR   // timing ablation only (results are wrong): what the per-step rendezvous costs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // ---- training tape -----------------------------------------------------------

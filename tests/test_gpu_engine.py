@@ -209,3 +209,27 @@ def test_h128_two_pass_kernel_vs_oracle(D, C, pool, N, T):
     lo, pr = _run(E, cfg, x, lengths, wk, 1)
     o = oracle.forward(ocfg, x, lengths, w)
     _check(lo[0], pr[0], o["logits"], o["probs"])
+
+
+@pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
+                                            (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
+                                            (24, 2, "mean", 2, 33, 1)])
+def test_paired_tile_kernel_matches_single_tile_kernel_and_oracle(D, C, pool, L, N, T):
+    """Un-masked inference over more than one tile runs the two-tiles-per-workgroup pipeline
+    (snn_forward_pair.hip); a batch of <= 32 curves runs lstm_fwd_kernel.  The same curves must give
+    bit-identical results through both (odd tile counts, partners of different length, 1..3 layers, both
+    poolings), and both must match the oracle."""
+    E = _eng()
+    H, S = 32, 2
+    cfg = E.Config(D, H, L, True, C, pool)
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    w = _random_model(cfg, 31, 0.15)
+    x, lengths = make_curves(32, N, T, D, min_len=1)
+    wk = E.prepare_weights(cfg, _t(w))
+    lo, pr = _run(E, cfg, x, lengths, wk, S)
+    for a in range(0, N, 32):
+        lo1, pr1 = _run(E, cfg, np.ascontiguousarray(x[:, a:a + 32]), lengths[a:a + 32], wk, S)
+        assert np.array_equal(lo1, lo[:, a:a + 32]) and np.array_equal(pr1, pr[:, a:a + 32])
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])
+    _check(lo[1], pr[1], o["logits"], o["probs"])
