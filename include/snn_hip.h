@@ -114,7 +114,7 @@ int snn_supported(const snn_cfg *cfg);        /* 1 if this build has forward ker
  *   len_sorted (n_tiles*32) length at sorted position (0 = padding)
  *   tile_T     (n_tiles)
  *   tile_off   (n_tiles+1)  float offset of each tile in the packed x buffer
- *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D rounded up to even)
+ *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D padded to the next supported width: 24, 26, 48, 76 or 78)
  * n_tiles = ceil(n_curves/32).  Lengths must be >= 1.
  */
 int snn_plan_build(const snn_cfg *cfg, const int32_t *lengths_host, int32_t n_curves,

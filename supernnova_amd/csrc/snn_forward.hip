@@ -16,10 +16,6 @@
 #include "snn_kernels.h"
 #include "snn_host.h"
 
-#ifndef SNN_FWD_WAVES
-#define SNN_FWD_WAVES 4  // waves per SIMD the un-masked inference kernels are register-allocated for (A/B: 2/3/4 -> 67.5/67.6/69.4 % of peak)
-#endif
-
 // ============================================================================
 // pack_x: one workgroup per tile, one thread per (t, curve), loop over features
 // ============================================================================
@@ -185,344 +181,6 @@ __global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ te
 }
 
 // ============================================================================
-// Persistent LSTM forward
-// ============================================================================
-template <int H, int KKI, int DIRS>
-struct PhaseCfg {
-    static constexpr int NT = H * 8;                 // threads per workgroup
-    static constexpr int ROWS = 2 * KKI;             // input rows staged per step
-    static constexpr int NF4 = ROWS * 8;             // float4 per step
-    static constexpr int NPT = (NF4 + NT - 1) / NT;  // float4 per thread per step
-};
-
-// One (layer, direction) pass over the tile's T steps.
-//   FIRST: input comes from the packed x tile; else from the previous layer's output.
-//   TRAIN: activations go to the tape (which also carries the layer outputs, unmasked; the
-//          between-layer mask is then applied by the consumer while staging).
-template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED>
-__device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
-                                          int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
-{
-    using PC = PhaseCfg<H, KKI, DIRS>;
-    constexpr int NT = PC::NT, NPT = PC::NPT, NF4 = PC::NF4, KKH = H / 2, KK = KKI + KKH;
-    constexpr int XIN_STRIDE = PC::ROWS * 32;  // floats per xin buffer for this phase
-    constexpr int NW = H / 8;
-    const FwdParams& y = p;  // D, L, C, pool, F
-    const MaskP& mk = p.mk;
-    const int ld = l * DIRS + d;
-    const bool last_layer = l == y.L - 1;
-    const int T = c.T;
-    const bool masked = MASKED && mk.mode != SNN_MASK_NONE;
-
-    // ---- weights -> registers (A operand of every MFMA of this phase)
-    float wreg[KK];
-    {
-        const float* A = c.wks + k_A + c.w * KK * 64 + c.lane;
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];
-    }
-    // variational W_hh row mask: forward direction only (variational_rnn.py:45, 224-238)
-    if (d == 0 && masked) {
-        const int r = c.lane & 31;
-        const float m = mask_whh(mk, c.s, y.L, H, l, (r >> 3) * H + 8 * c.w + (r & 7));
-#pragma unroll
-        for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
-    }
-    // b_ih + b_hh in C/D register order, parked in LDS (re-read per step: 4 broadcast ds_read_b128)
-    if (c.cl < 16) {
-        const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
-        bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
-    }
-    const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
-
-    // ---- per-lane masks
-    const int j0 = 8 * c.w + 4 * c.hf;  // first of this lane's 4 hidden units
-    float mmid[4] = {1.f, 1.f, 1.f, 1.f};
-    const bool mid_step = masked && mk.mid_T > 1;  // per-step between-layer mask (torch.nn.LSTM dropout, train)
-    if (!TRAIN && !last_layer && masked && c.orig >= 0 && !mid_step) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            mmid[u] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, c.orig, d * H + j0 + u);
-    }
-    // mask registers of the staging threads: layer 0 input mask, or (TRAIN) the between-layer mask
-    float min_[NPT][4];
-#pragma unroll
-    for (int i = 0; i < NPT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
-    if (masked && (FIRST || (TRAIN && !mid_step))) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const int k = f >> 3, c4 = (f & 7) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                    if (o >= 0) {
-                        if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
-                        else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- input source
-    const float* in0;  // FIRST: tile base; TRAIN: tape; else y buffer of layer l-1
-    if (FIRST) in0 = p.xp + p.tile_off[c.tile];
-    else if (TRAIN) in0 = c.tape;
-    else in0 = c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
-    float* yout = (last_layer || TRAIN) ? nullptr
-                                        : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
-    float* tape_ld = TRAIN ? c.tape + (int64_t)ld * p.max_T * tape_step_floats(H) : nullptr;
-
-    auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const float* src;
-                if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
-                else {
-                    const int dd = f / (H * 8), ff = f - dd * (H * 8);
-                    if (TRAIN)
-                        src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
-                    else
-                        src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
-                }
-                pre[i] = *reinterpret_cast<const f32x4*>(src);
-            }
-        }
-    };
-    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT], int t) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                f32x4 v = pre[i];
-                if (FIRST || TRAIN) {
-                    if (!FIRST && mid_step) {
-                        const int k = f >> 3, c4 = (f & 7) * 4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                            if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
-                    }
-                }
-                *reinterpret_cast<f32x4*>(dstbuf + f * 4) = v;
-            }
-        }
-    };
-
-    // ---- state
-    float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f}, hsum[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        f32x4 pre[NPT];
-        const int t0 = d == 0 ? 0 : T - 1;
-        load_step(t0, pre);
-        store_step(xin, pre, t0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hb[(j0 + u) * 32 + c.cl] = 0.0f;
-    }
-    lds_barrier();
-
-    for (int step = 0; step < T; ++step) {
-        const int t = d == 0 ? step : T - 1 - step;
-        const int cur = step & 1;
-        f32x4 pre[NPT];
-        const bool more = step + 1 < T;
-        const int tn = d == 0 ? t + 1 : t - 1;
-        if (more) load_step(tn, pre);
-
-        f32x16 acc = *binit_p;
-        const float* xc = xin + cur * XIN_STRIDE + c.lane;
-#pragma unroll
-        for (int kk = 0; kk < KKI; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], xc[kk * 64], acc, 0, 0, 0);
-        const float* hc = hb + cur * (H * 32) + c.lane;
-#pragma unroll
-        for (int kk = 0; kk < KKH; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[KKI + kk], hc[kk * 64], acc, 0, 0, 0);
-
-        const bool valid = t < c.len;
-        float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
-        float outv[4];
-        float* tp = TRAIN ? tape_ld + (int64_t)t * tape_step_floats(H) + j0 * 32 + c.cl : nullptr;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float ig = snn_sigmoid(acc[u]);
-            const float fg = snn_sigmoid(acc[4 + u]);
-            const float gg = snn_tanh(acc[8 + u]);
-            const float og = snn_sigmoid(acc[12 + u]);
-            // explicit contraction: every copy of the loop body (peeled last step, TRAIN variant) must round the
-            // same way, so a curve's result does not depend on the tile it lands in
-            const float cn = fmaf(fg, cst[u], __fmul_rn(ig, gg));
-            const float hv = og * snn_tanh(cn);
-            cst[u] = valid ? cn : cst[u];
-            hst[u] = valid ? hv : hst[u];
-            outv[u] = valid ? hv : 0.0f;
-            hn[u * 32] = hst[u];
-            if (TRAIN) {
-                tp[(0 * H + u) * 32] = ig;
-                tp[(1 * H + u) * 32] = fg;
-                tp[(2 * H + u) * 32] = gg;
-                tp[(3 * H + u) * 32] = og;
-                tp[(4 * H + u) * 32] = cn;
-                tp[(5 * H + u) * 32] = outv[u];
-            }
-        }
-        if (last_layer) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) hsum[u] += outv[u];
-        } else if (!TRAIN) {
-#ifdef SNN_ABL_NOYST   // timing ablation only: no layer-output stores
-            if (p.n_curves < 0)
-#endif
-            {
-            float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
-            if (mid_step && c.orig >= 0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    yo[u * 32] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, t, c.orig, d * H + j0 + u), outv[u]);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mmid[u], outv[u]);
-            }
-            }
-        }
-        if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
-        lds_barrier();
-    }
-
-    // ---- head contribution of this phase
-    const bool contributes = y.pool == SNN_POOL_STANDARD || last_layer;
-    if (contributes) {
-        float feat[4];
-        int fidx[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (y.pool == SNN_POOL_MEAN) {
-                feat[u] = __fdiv_rn(hsum[u], (float)(c.len > 0 ? c.len : 1));
-                fidx[u] = d * H + j0 + u;
-            } else {
-                feat[u] = hst[u];
-                fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
-            }
-        }
-        if (masked && c.orig >= 0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) feat[u] = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, c.orig, fidx[u]), feat[u]);
-        }
-        if (TRAIN) {
-            float* fs = c.tape + (int64_t)y.L * DIRS * p.max_T * tape_step_floats(H);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fs[fidx[u] * 32 + c.cl] = feat[u];
-        }
-        const float* Wo = c.wks + k_head_w;
-        for (int q = 0; q < y.C; ++q) {
-            float a = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a = fmaf(Wo[q * y.F + fidx[u]], feat[u], a);
-            a += __shfl_xor(a, 32);
-            if (c.hf == 0) part[(c.w * y.C + q) * 32 + c.cl] = a;
-        }
-        __syncthreads();
-        for (int idx = c.tid; idx < y.C * 32; idx += NT) {
-            const int q = idx >> 5, cc = idx & 31;
-            float a = logit[idx];
-            for (int w = 0; w < H / 8; ++w) a += part[(w * y.C + q) * 32 + cc];
-            logit[idx] = a;
-        }
-    }
-    __syncthreads();  // also publishes this phase's y / tape stores to the workgroup
-}
-
-template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED>
-__global__ void __launch_bounds__(H * 8, (TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) lstm_fwd_kernel(const FwdParams p)
-{
-    constexpr int NT = H * 8;
-    constexpr int KKI1 = DIRS * H / 2;
-    constexpr int ROWS = (2 * KKI0 > 2 * KKI1) ? 2 * KKI0 : 2 * KKI1;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const FwdParams& y = p;
-    // kernel-layout offsets of snn_layout.h, compile-time given the template parameters
-    constexpr int NW = H / 8;
-    constexpr int BLK0 = NW * (KKI0 + H / 2) * 64 + 2 * NW * 32;  // one (layer 0, dir) block
-    constexpr int BLK1 = NW * (KKI1 + H / 2) * 64 + 2 * NW * 32;  // one (layer >= 1, dir) block
-    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
-    float* xin = smem;                      // [2][ROWS*32]
-    float* hb = xin + 2 * ROWS * 32;        // [2][H*32]
-    float* part = hb + 2 * H * 32;          // [NW][C][32]
-    float* logit = part + (H / 8) * y.C * 32;  // [C][32]
-    float* bl = logit + y.C * 32;               // [NW][2][16] bias image of the running phase
-    int* item_slot = reinterpret_cast<int*>(bl + NW * 32);
-
-    ItemCtx c;
-    c.tid = threadIdx.x;
-    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    c.lane = threadIdx.x & 63;
-    c.cl = c.lane & 31;
-    c.hf = c.lane >> 5;
-    c.ybase = p.yscratch + (int64_t)blockIdx.x * p.nbuf * p.y_buf_floats;
-    const int64_t n_items = (int64_t)p.n_tiles * p.n_samples;
-
-    for (;;) {
-        if (c.tid == 0) *item_slot = (int)atomicAdd(p.counter, 1u);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(*item_slot);
-        if (item >= n_items) break;
-        c.tile = item / p.n_samples;
-        c.s = item - c.tile * p.n_samples;
-        c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
-        const int pos = c.tile * SNN_TILE + c.cl;
-        c.len = p.len_sorted[pos];
-        c.orig = p.order[pos];
-        c.wks = p.wk + (int64_t)c.s * p.wk_stride;
-        c.tape = TRAIN ? p.tape + (int64_t)c.tile * p.tape_tile : nullptr;
-        for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
-        __syncthreads();  // item_slot consumed, logit zeroed
-
-        for (int l = 0; l < y.L; ++l) {
-            for (int d = 0; d < DIRS; ++d) {
-                if (l == 0) {
-                    const int kA = d * BLK0;
-                    run_phase<H, KKI0, DIRS, true, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w,
-                                                                  xin, hb, part, logit, bl);
-                } else {
-                    const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    run_phase<H, KKI1, DIRS, false, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w,
-                                                                   xin, hb, part, logit, bl);
-                }
-            }
-        }
-
-        // ---- head bias + softmax, one thread per curve
-        if (c.tid < 32) {
-            const int orig = c.orig;  // tid < 32: lane == cl
-            if (orig >= 0) {
-                const float* bo = c.wks + k_head_w + y.C * y.F;
-                float mx = -INFINITY;
-                for (int q = 0; q < y.C; ++q) mx = fmaxf(mx, logit[q * 32 + c.tid] + bo[q]);
-                float z = 0.0f;
-                for (int q = 0; q < y.C; ++q) z += expf(logit[q * 32 + c.tid] + bo[q] - mx);
-                const int64_t o = (int64_t)c.s * p.os_s + (int64_t)orig * p.os_n;
-                for (int q = 0; q < y.C; ++q) {
-                    const float lg = logit[q * 32 + c.tid] + bo[q];
-                    if (p.out_logits) p.out_logits[o + q] = lg;
-                    if (p.out_probs) p.out_probs[o + q] = __fdiv_rn(expf(lg - mx), z);
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ============================================================================
 // host side
 // ============================================================================
 static thread_local char g_err[512] = "";
@@ -567,30 +225,27 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
     return rc ? rc : y.F;
 }
 
-// ---- forward kernel registry: (H, KKI0, DIRS) instantiations ----------------
+// ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; };
 struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; };
-fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs);   // snn_forward_big.hip
-fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);  // snn_forward_pair.hip
-#define FWD_ENTRY(H, K, Dd)                                                                          \
-    {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
-     lstm_fwd_kernel<H, K, Dd, true, true>, false}
-static const FwdEntry g_fwd[] = {
-    FWD_ENTRY(32, 12, 2),  // D = 23..24  (4 filters)
-    FWD_ENTRY(32, 13, 2),  // D = 25..26  (4 filters + redshift)
-    FWD_ENTRY(32, 12, 1),
-    FWD_ENTRY(64, 12, 2),
-    FWD_ENTRY(64, 13, 2),
-};
+const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
+const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
+fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pair.hip
 static const FwdEntry* find_fwd(const SnnLayout& y)
 {
-    for (const FwdEntry& e : g_fwd)
-        if (e.H == y.H && e.KKI0 == y.KKI[0] && e.dirs == y.dirs) return &e;
-    // hidden sizes whose weights do not fit the register file: two-pass kernel (inference only)
-    static thread_local FwdEntry big;
-    if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs)) {
-        big = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, nullptr, true};
-        return &big;
+    static thread_local FwdEntry ent;
+    const FwdSmallEntry* e = y.H == 32 ? snn_fwd_small_h32(y.KKI[0], y.dirs)
+                           : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
+    if (e) {
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false};
+        return &ent;
+    }
+    // hidden sizes whose weights do not fit the register file: two-pass kernel
+    if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, false)) {
+        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true};
+        return &ent;
     }
     return nullptr;
 }
@@ -668,7 +323,7 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
                          float* kl_terms, hipStream_t st)
 {
-    if (y.PK != y.k_head_b + y.C || (y.D & 1))  // padding floats exist: define them
+    if (y.PK != y.k_head_b + y.C || y.Dp != y.D)  // padding floats exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
     hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
                        offset, prior, wk, kl ? kl_terms : nullptr);

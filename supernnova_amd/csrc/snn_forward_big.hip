@@ -349,13 +349,22 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
 
 // ---- registry hooks used by snn_forward.hip -------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs)
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train)
 {
+    if (train) return nullptr;
     if (H == 128 && dirs == 2) {
-        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 2>;   // D = 75..76 (6 filters)
-        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 2>;   // D = 77..78 (6 filters + redshift)
-        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 2>;   // D = 23..24
-        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 2>;   // D = 25..26
+        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 2>;   // D <= 24
+        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 2>;   // D <= 26
+        if (KKI0 == 24) return lstm_fwd_big_kernel<128, 24, 2>;   // D <= 48
+        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 2>;   // D <= 76 (6 filters)
+        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 2>;   // D <= 78 (6 filters + redshift)
+    }
+    if (H == 128 && dirs == 1) {
+        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 1>;
+        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 1>;
+        if (KKI0 == 24) return lstm_fwd_big_kernel<128, 24, 1>;
+        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 1>;
+        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 1>;
     }
     return nullptr;
 }

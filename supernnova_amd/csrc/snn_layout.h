@@ -8,7 +8,8 @@
 // straight into MFMA A-operand registers):
 //   per (layer, dir):
 //     A image  [NW][KK][64]   A[w][kk][lane] = Wcat[row(w, lane&31)][2*kk + (lane>>5)]
-//              Wcat = [w_ih | zero pad to even | w_hh] (4H x (2*KKI + H)),
+//              Wcat = [w_ih | zero pad to 2*KKI columns | w_hh] (4H x (2*KKI + H)), KKI of layer 0 from
+//              snn_kki0_bucket(D),
 //              row(w, r) = (r>>3)*H + 8*w + (r&7)   (gate r>>3 of hidden unit 8w + (r&7)),
 //              so the 32x32 MFMA tile of wave w holds the 4 gates of 8 units and each
 //              lane of the C/D tile ends up with all 4 gates of 4 units;
@@ -24,7 +25,7 @@
 
 struct SnnLayout {
     int D, H, L, dirs, C, pool, F;
-    int Dp;  // D rounded up to even
+    int Dp;  // D padded to the layer-0 k-step bucket (2 * snn_kki0_bucket(D))
     int NW;  // waves per workgroup = H / 8
     int I[SNN_MAX_LAYERS];    // input width of layer l
     int KKI[SNN_MAX_LAYERS];  // ceil(I/2): MFMA k-steps of the input part
@@ -36,18 +37,30 @@ struct SnnLayout {
     int n_tensors;  // sampled tensors: 4*L*dirs + 1
 };
 
+// MFMA k-steps of the layer-0 input part.  The kernels are instantiated for a few widths; an input size in
+// between is zero-padded up to the next one (zero weight columns x zero inputs: results unchanged), so any
+// feature count up to SNN_MAX_D runs: 4 filters (D = 24, +2 with redshift), 5 filters (42/44), 6 filters (76/78).
+#define SNN_MAX_D 78
+static inline int snn_kki0_bucket(int D)
+{
+    static const int buckets[] = {12, 13, 24, 38, 39};
+    for (int i = 0; i < 5; ++i)
+        if (D <= 2 * buckets[i]) return buckets[i];
+    return (D + 1) / 2;
+}
+
 static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool)
 {
     if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1)
         return -1;
     y->D = D; y->H = H; y->L = L; y->dirs = bidir ? 2 : 1; y->C = C; y->pool = pool;
     y->F = pool == 0 ? y->dirs * H : y->dirs * H * L;
-    y->Dp = (D + 1) & ~1;
+    y->Dp = 2 * snn_kki0_bucket(D);
     y->NW = H / 8;
     int64_t c = 0, k = 0;
     for (int l = 0; l < L; ++l) {
         y->I[l] = l == 0 ? D : y->dirs * H;
-        y->KKI[l] = (y->I[l] + 1) / 2;
+        y->KKI[l] = l == 0 ? y->Dp / 2 : (y->I[l] + 1) / 2;
         y->KK[l] = y->KKI[l] + H / 2;
         for (int d = 0; d < y->dirs; ++d) {
             int ld = l * y->dirs + d;

@@ -233,3 +233,31 @@ def test_paired_tile_kernel_matches_single_tile_kernel_and_oracle(D, C, pool, L,
     o = oracle.forward(ocfg, x, lengths, w)
     _check(lo[0], pr[0], o["logits"], o["probs"])
     _check(lo[1], pr[1], o["logits"], o["probs"])
+
+
+@pytest.mark.parametrize("D,H,bidir", [(8, 32, True), (14, 64, True), (42, 32, True), (44, 64, False), (76, 32, True),
+                                       (78, 64, True), (42, 128, True), (30, 32, False), (78, 128, False)])
+def test_feature_width_buckets_vs_oracle(D, H, bidir):
+    """Any input width up to 78 runs: the layer-0 k-steps are zero-padded up to the next instantiated width
+    (snn_layout.h: 24, 26, 48, 76, 78), for 1..6 filters with or without redshift, both direction counts."""
+    E = _eng()
+    L, C, S, N, T = 2, 3, 1, 45, 11
+    cfg = E.Config(D, H, L, bidir, C, "mean")
+    assert cfg.supported()
+    ocfg = oracle.make_cfg(D, H, L, bidir, C, "mean")
+    w = _random_model(cfg, 41, 0.12)
+    x, lengths = make_curves(42, N, T, D, min_len=1)
+    lo, pr = _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(w)), S)
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])
+
+
+def test_unsupported_shapes_fail_loudly():
+    E = _eng()
+    from supernnova_amd import _lib
+    for cfg in (E.Config(80, 32, 2, True, 2, "mean"), E.Config(24, 48, 2, True, 2, "mean"),
+                E.Config(24, 256, 2, True, 2, "mean")):
+        assert not cfg.supported()
+        with pytest.raises(_lib.SnnError):
+            E.lstm_forward_workspace_bytes(cfg, 10) if hasattr(E, "lstm_forward_workspace_bytes") else \
+                _lib.check(_lib.load().snn_lstm_forward_workspace_bytes(__import__("ctypes").byref(cfg.c), 10), "ws")

@@ -181,3 +181,48 @@ def test_adam_kernel_matches_reference_update(model):
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     E.adam_step(p, gr, m, v, 1, float(g["lr"]), weight_decay=float(g["weight_decay"]))
     np.testing.assert_allclose(p.cpu().numpy(), flat(g["sd1"], keys), atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize("D,H,L,bidir,pool,C", [(24, 32, 2, True, "mean", 2), (42, 32, 2, True, "mean", 3),
+                                                (78, 32, 2, True, "standard", 5), (24, 64, 2, True, "mean", 2),
+                                                (78, 64, 2, True, "mean", 14), (26, 32, 1, True, "mean", 2),
+                                                (24, 32, 3, True, "standard", 2), (44, 32, 2, False, "mean", 2),
+                                                (24, 64, 2, False, "standard", 3)])
+def test_backward_shapes_vs_autograd(D, H, L, bidir, pool, C):
+    """Gradients of CE(logits, target) w.r.t. every weight, for shapes beyond the reference fixtures, against
+    autograd through the stock-PyTorch port (aten::lstm on the CPU: what the reference differentiates)."""
+    from supernnova_amd import engine as E
+    from oracle import torch_port as tp
+    from util import make_curves
+    dirs = 2 if bidir else 1
+    cfg = E.Config(D, H, L, bidir, C, pool)
+    g = np.random.default_rng(61)
+    N, T = 50, 13
+    x, lengths = make_curves(62, N, T, D, min_len=1)
+    order = np.argsort(-lengths, kind="stable")
+    x, lengths = np.ascontiguousarray(x[:, order]), lengths[order]
+    target = g.integers(0, C, N)
+    keys = layout.vanilla_keys(L, dirs)
+    shapes = []
+    for l in range(L):
+        I = D if l == 0 else dirs * H
+        shapes += [(4 * H, I), (4 * H, H), (4 * H,), (4 * H,)] * dirs
+    shapes += [(C, cfg.F), (C,)]
+    sd = {k: torch.from_numpy(g.uniform(-0.2, 0.2, s).astype(np.float32)).requires_grad_() for k, s in zip(keys, shapes)}
+    packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths.astype(np.int64)))
+    ref_logits = tp.vanilla_forward(sd, packed, hidden=H, num_layers=L, bidirectional=bidir, pool=pool)
+    loss = torch.nn.functional.cross_entropy(ref_logits, torch.from_numpy(target))
+    loss.backward()
+    plan = E.Plan(cfg, lengths, DEV)
+    xp = E.pack_x(cfg, plan, _t(x))
+    wk = E.prepare_weights(cfg, _t(np.concatenate([sd[k].detach().numpy().ravel() for k in keys])))
+    logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, None)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.detach().numpy(), atol=LOGIT_ATOL, rtol=0)
+    ce, dlogits = E.ce_loss_grad(logits, _t(target, np.int64))
+    gw = E.lstm_backward(cfg, plan, xp, wk, tape, dlogits, None).cpu().numpy()
+    assert abs(float(ce) - float(loss)) < 2e-6 * max(1.0, abs(float(loss)))
+    off = 0
+    for k in keys:
+        n = sd[k].numel()
+        _grad_check(gw[off:off + n], sd[k].grad.numpy(), k)
+        off += n

@@ -43,7 +43,9 @@ def test_sizes_and_errors_through_abi():
     assert cfg.PK >= cfg.P and cfg.supported()
     assert E.Config(26, 32, 2, True, 3, "standard").F == 128
     assert E.Config(78, 128, 2, True, 14, "mean").supported()      # two-pass kernel (config 5)
-    assert not E.Config(50, 128, 2, True, 14, "mean").supported()
+    assert E.Config(50, 128, 2, True, 14, "mean").supported()       # any width <= 78 (zero-padded k-steps)
+    assert not E.Config(80, 128, 2, True, 14, "mean").supported()
+    assert not E.Config(24, 48, 2, True, 2, "mean").supported()     # hidden sizes: 32, 64, 128
     with pytest.raises(_lib.SnnError):
         E.Config(24, 30, 2, True, 2, "mean").P     # H % 8 != 0
     with pytest.raises(_lib.SnnError):
