@@ -19,7 +19,7 @@
 #include "snn_host.h"
 
 // One (layer, direction) phase.  TP = row tiles per wave handled by one input pass.
-template <int H, int KKI, int DIRS, bool FIRST, int TP>
+template <int H, int KKI, int DIRS, bool FIRST, int TP, bool TRAIN>
 __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
                                           int k_head_w, float* xin, float* hb, float* part, float* logit,
                                           float* mlds, float* gx)
@@ -35,8 +35,11 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     const bool last_layer = l == y.L - 1;
     const int T = c.T;
     const float* Abase = c.wks + k_A;
-    const float* in0 = FIRST ? p.xp + p.tile_off[c.tile] : c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
-    float* yout = last_layer ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+    // TRAIN: the layer outputs live on the tape (unmasked); the between-layer mask is applied while staging
+    const float* in0 = FIRST ? p.xp + p.tile_off[c.tile] : TRAIN ? c.tape : c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
+    float* yout = (last_layer || TRAIN) ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
+    float* tape_ld = TRAIN ? c.tape + (int64_t)ld * p.max_T * tape_step_floats(H) : nullptr;
+    const bool mid_step = masked && mk.mid_T > 1;   // per-step between-layer mask (torch.nn.LSTM dropout in train mode)
 
     // input-mask registers of the staging threads (layer 0, variational)
     float min_[NPT][4];
@@ -44,7 +47,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     for (int i = 0; i < NPT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
-    if (FIRST && masked) {
+    if (masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
@@ -53,7 +56,10 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                    if (o >= 0 && k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k);
+                    if (o >= 0) {
+                        if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
+                        else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
+                    }
                 }
             }
         }
@@ -67,21 +73,31 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
                 if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
                 else {
                     const int dd = f / (H * 8), ff = f - dd * (H * 8);
-                    src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
+                    if (TRAIN) src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
+                    else src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
                 }
                 pre[i] = *reinterpret_cast<const f32x4*>(src);
             }
         }
     };
-    auto store_step = [&](float* dst, const f32x4 (&pre)[NPT]) {
+    auto store_step = [&](float* dst, const f32x4 (&pre)[NPT], int t) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
             if (f < NF4) {
                 f32x4 v = pre[i];
-                if (FIRST) {
+                if (FIRST || TRAIN) {
+                    if (!FIRST && mid_step) {
+                        const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                            if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                    }
                 }
                 *reinterpret_cast<f32x4*>(dst + f * 4) = v;
             }
@@ -105,7 +121,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
         {
             f32x4 pre[NPT];
             load_step(0, pre);
-            store_step(xin, pre);
+            store_step(xin, pre, 0);
         }
         lds_barrier();
         for (int t = 0; t < T; ++t) {
@@ -129,7 +145,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) g[i * 64] = acc[r][i];
             }
-            if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre);
+            if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, t + 1);
             lds_barrier();
         }
     }
@@ -151,7 +167,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
         }
     }
     // locked between-layer mask of this lane's units, parked in LDS: mlds[unit][curve]
-    const bool use_mid = masked && !last_layer;
+    const bool use_mid = masked && !last_layer && !TRAIN;
     if (use_mid) {
         for (int idx = c.tid; idx < H * 32; idx += NT) {
             const int j = idx >> 5, cc = idx & 31;
@@ -208,6 +224,15 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
                 hst[r][u] = valid ? hv : hst[r][u];
                 outv[u] = valid ? hv : 0.0f;
                 hn[u * 32] = hst[r][u];
+                if (TRAIN) {
+                    float* tp = tape_ld + (int64_t)t * tape_step_floats(H) + (j0 + u) * 32 + c.cl;
+                    tp[0 * H * 32] = ig;
+                    tp[1 * H * 32] = fg;
+                    tp[2 * H * 32] = gg;
+                    tp[3 * H * 32] = og;
+                    tp[4 * H * 32] = cn;
+                    tp[5 * H * 32] = outv[u];
+                }
             }
             // the next step's Gx for this tile goes straight into the now-free accumulator
             if (more) {
@@ -218,7 +243,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
             if (last_layer) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) hsum[r][u] += outv[u];
-            } else {
+            } else if (!TRAIN) {
                 float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -249,6 +274,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
                         fidx = (j0 + u) * (y.L * DIRS) + ld;
                     }
                     if (masked && c.orig >= 0) feat = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, c.orig, fidx), feat);
+                    if (TRAIN && q == 0) c.tape[(int64_t)y.L * DIRS * p.max_T * tape_step_floats(H) + fidx * 32 + c.cl] = feat;
                     a = fmaf(Wo[q * y.F + fidx], feat, a);
                 }
             }
@@ -266,7 +292,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     __syncthreads();
 }
 
-template <int H, int KKI0, int DIRS>
+template <int H, int KKI0, int DIRS, bool TRAIN>
 __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
 {
     constexpr int NT = 256;
@@ -291,7 +317,6 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
     c.lane = threadIdx.x & 63;
     c.cl = c.lane & 31;
     c.hf = c.lane >> 5;
-    c.tape = nullptr;
     // per-workgroup scratch: [nbuf y buffers][Gx: max_T * NWT * 1024]
     const int64_t gx_floats = (int64_t)p.max_T * NWT * 1024;
     float* wg = p.yscratch + (int64_t)blockIdx.x * (p.nbuf * p.y_buf_floats + gx_floats);
@@ -311,6 +336,7 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
         c.len = p.len_sorted[pos];
         c.orig = p.order[pos];
         c.wks = p.wk + (int64_t)c.s * p.wk_stride;
+        c.tape = TRAIN ? p.tape + (int64_t)c.tile * p.tape_tile : nullptr;
         for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
         __syncthreads();
 
@@ -318,11 +344,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 1)>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
+                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 1), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
                                                                             k_head_w, xin, hb, part, logit, mlds, gx);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 1)>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
+                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 1), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
                                                                              k_head_w, xin, hb, part, logit, mlds, gx);
                 }
             }
@@ -349,22 +375,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
 
 // ---- registry hooks used by snn_forward.hip -------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
+#define BIG_PICK(K, Dd) if (KKI0 == K && dirs == Dd) return train ? lstm_fwd_big_kernel<128, K, Dd, true> : lstm_fwd_big_kernel<128, K, Dd, false>
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train)
 {
-    if (train) return nullptr;
-    if (H == 128 && dirs == 2) {
-        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 2>;   // D <= 24
-        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 2>;   // D <= 26
-        if (KKI0 == 24) return lstm_fwd_big_kernel<128, 24, 2>;   // D <= 48
-        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 2>;   // D <= 76 (6 filters)
-        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 2>;   // D <= 78 (6 filters + redshift)
-    }
-    if (H == 128 && dirs == 1) {
-        if (KKI0 == 12) return lstm_fwd_big_kernel<128, 12, 1>;
-        if (KKI0 == 13) return lstm_fwd_big_kernel<128, 13, 1>;
-        if (KKI0 == 24) return lstm_fwd_big_kernel<128, 24, 1>;
-        if (KKI0 == 38) return lstm_fwd_big_kernel<128, 38, 1>;
-        if (KKI0 == 39) return lstm_fwd_big_kernel<128, 39, 1>;
-    }
+    if (H != 128) return nullptr;
+    BIG_PICK(12, 2); BIG_PICK(13, 2); BIG_PICK(24, 2); BIG_PICK(38, 2); BIG_PICK(39, 2);   // D <= 24, 26, 48, 76, 78
+    BIG_PICK(12, 1); BIG_PICK(13, 1); BIG_PICK(24, 1); BIG_PICK(38, 1); BIG_PICK(39, 1);
     return nullptr;
 }

@@ -36,12 +36,18 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int64_t P, int n_slabs
 }
 
 // ---- backward kernel registry --------------------------------------------------
-const BwdEntry* snn_bwd_small_h32(int KKI0, int dirs);   // snn_bwd_h32.hip
-const BwdEntry* snn_bwd_small_h64(int KKI0, int dirs);   // snn_bwd_h64.hip
+const BwdEntry* snn_bwd_small_h32(int KKI0, int dirs);   // snn_bwd_h32.hip: fused kernel, H = 32
 static const BwdEntry* find_bwd(const SnnLayout& y)
 {
-    return y.H == 32 ? snn_bwd_small_h32(y.KKI[0], y.dirs) : y.H == 64 ? snn_bwd_small_h64(y.KKI[0], y.dirs) : nullptr;
+    return y.H == 32 ? snn_bwd_small_h32(y.KKI[0], y.dirs) : nullptr;
 }
+// H = 64, 128: recurrent kernel + deferred GEMMs (snn_train_big.hip)
+bool snn_bwd_big_supported(const SnnLayout& y);
+int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T);
+int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
+                          const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles, int32_t max_T,
+                          const float* wk, const MaskP& mk, const float* tape, int64_t tape_tile, const float* dlogits,
+                          float* dflat, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 static const int BWD_MAX_GRID = 256;
 
@@ -58,6 +64,11 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
+    if (!find_bwd(y)) {
+        if (snn_bwd_big_supported(y)) return snn_bwd_big_workspace_bytes(y, n_tiles, max_T);
+        snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs);
+        return SNN_ERR_UNSUPPORTED;
+    }
     const int grid = std::min(n_tiles, BWD_MAX_GRID);
     return (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * y.dirs * max_T * y.H * 32);
 }
@@ -72,7 +83,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
     const BwdEntry* e = find_bwd(y);
-    if (!e) { snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (!e && !snn_bwd_big_supported(y)) { snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !tape || !dlogits || !dflat || !workspace) {
         snn_set_error("snn_lstm_backward: null pointer");
         return SNN_ERR_ARG;
@@ -83,6 +94,13 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     }
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (tape_floats < tape_tile * n_tiles) { snn_set_error("snn_lstm_backward: tape too small"); return SNN_ERR_ARG; }
+    if (!e) {
+        MaskP mk;
+        rc = snn_masks_to_device(masks, max_T, &mk);
+        if (rc) return rc;
+        return snn_lstm_backward_big(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, mk, tape,
+                                     tape_tile, dlogits, dflat, accumulate, workspace, workspace_bytes, stream);
+    }
     const int grid = std::min(n_tiles, BWD_MAX_GRID);
     const int64_t need = (int64_t)sizeof(float) * grid * (y.P + (int64_t)2 * y.dirs * y.dirs * max_T * y.H * 32);
     if (workspace_bytes < need) {

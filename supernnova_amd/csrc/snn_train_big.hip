@@ -1,0 +1,507 @@
+// snn_train_big.hip -- BPTT for hidden sizes 64 and 128, where the fused kernel of snn_bwd_small.h does not
+// fit (its per-wave register image of [W_hh | W_ih]^T plus the dW accumulators needs > 512 VGPRs, its LDS
+// image > 160 KB).  The work is split the way the forward's two-pass kernel splits it -- only the recurrent
+// product stays inside the sequential loop, everything that is a plain GEMM over (curve, step) is deferred:
+//
+//   bwd_prep_kernel   W_hh^T / W_ih^T as MFMA A-operand images, gathered once from the forward's weight image
+//   head_*_kernel     output layer backward: dfeat per tile, dW_out / db_out
+//   per layer, top down:
+//     bwd_rec_kernel  one workgroup per (tile, direction): gate gradients from the tape, dh_{t-1} = W_hh^T dG_t
+//                     with W_hh^T resident in registers (256 VGPRs at H = 128); dG_t streamed to HBM
+//     bwd_dx_kernel   (layer > 0) dy of the layer below = mask (.) sum_dir W_ih^T dG_t, tiles x time in parallel
+//     bwd_dw_kernel   dW_ih, dW_hh, db = sum over (tile, t, curve) of dG_t [h_{t-1} | x_t | 1]^T, split over
+//                     gate-row groups and chunks of (tile, t); chunk partials summed in fixed order
+// Replaces autograd's traversal of aten::lstm in `loss.backward()` (utils/training_utils.py:523), as
+// snn_lstm_backward does for H = 32.  Deterministic: no atomics, fixed summation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+
+#include "snn_kernels.h"
+#include "snn_host.h"
+
+#define HIP_CHECK(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            snn_set_error("%s failed: %s", #expr, hipGetErrorString(e_));           \
+            return SNN_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+
+struct Bwd2Params {
+    SnnLayout lay;
+    const float* xp;
+    const int32_t* len_sorted;
+    const int32_t* order;
+    const int32_t* tile_T;
+    const int64_t* tile_off;
+    int n_curves, n_tiles, max_T;
+    const float* wk;
+    MaskP mk;
+    const float* tape;
+    int64_t tape_tile;
+    const float* dlogits;
+    float* WT;                                      // transposed weight images
+    int64_t wt_hh[SNN_MAX_LD], wt_ih[SNN_MAX_LD];   // float offsets into WT
+    float* dfeat;                                   // [tile][F][32]
+    float* dG;                                      // [tile][dir][max_T][4H][32], the layer being processed
+    const float* dy_in;                             // [tile][dir][max_T][H][32]: d loss / d (outputs of this layer)
+    float* dy_out;                                  // same layout, for the layer below
+    float* slabs;                                   // [n_chunks][P]
+    float* dflat;
+    int accumulate;
+};
+
+constexpr int PAD = 33;   // LDS row stride of transposed-read images
+
+// ---- weight images -------------------------------------------------------------------------------------
+// WT_hh[ld][mt][kk][lane] = W_hh_eff[R = 2kk + (lane >> 5)][j = 32 mt + (lane & 31)]       (mt < H/32, kk < 2H)
+// WT_ih[ld][mt][kk][lane] = W_ih[R][f = 32 mt + (lane & 31)]                               (layer >= 1, mt < I/32)
+__global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
+{
+    const SnnLayout& y = p.lay;
+    const int ld = blockIdx.y >> 1, which = blockIdx.y & 1;   // 0: hh, 1: ih
+    const int l = ld / y.dirs, d = ld - l * y.dirs;
+    const int H = y.H, I = y.I[l];
+    if (which == 1 && l == 0) return;
+    const int cols = which == 0 ? H : I;
+    const int64_t n = (int64_t)(cols / 32) * 2 * H * 64;
+    const TensorGeom g = tensor_geom(y, 4 * ld + (which == 0 ? 1 : 0));
+    float* dst = p.WT + (which == 0 ? p.wt_hh[ld] : p.wt_ih[ld]);
+    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const int kk = (int)((idx >> 6) % (2 * H));
+        const int mt = (int)(idx / ((int64_t)2 * H * 64));
+        const int R = 2 * kk + (lane >> 5), col = 32 * mt + (lane & 31);
+        float v = p.wk[kernel_index(y, g, (int64_t)R * cols + col)];
+        if (which == 0 && d == 0 && masked) v = __fmul_rn(mask_whh(p.mk, 0, y.L, H, l, R), v);   // variational_rnn.py:224-238
+        dst[idx] = v;
+    }
+}
+
+// ---- output layer backward ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_dfeat_kernel(const Bwd2Params p)
+{
+    const SnnLayout& y = p.lay;
+    const int tile = blockIdx.x;
+    const float* Wo = p.wk + y.k_head_w;
+    float* out = p.dfeat + (int64_t)tile * y.F * 32;
+    for (int idx = threadIdx.x; idx < y.F * 32; idx += blockDim.x) {
+        const int f = idx >> 5, c = idx & 31;
+        const int o = p.order[tile * SNN_TILE + c];
+        float s = 0.0f;
+        if (o >= 0) {
+            for (int q = 0; q < y.C; ++q) s = fmaf(Wo[q * y.F + f], p.dlogits[(int64_t)o * y.C + q], s);
+            if (p.mk.mode != SNN_MASK_NONE) s = __fmul_rn(mask_out(p.mk, 0, p.n_curves, y.F, o, f), s);
+        }
+        out[idx] = s;
+    }
+}
+
+// dW_out[q][f] = sum over curves (fixed order) dlogits[curve][q] feat[curve][f];  db_out[q] = sum dlogits
+__global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p)
+{
+    const SnnLayout& y = p.lay;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= y.C * y.F + y.C) return;
+    const int64_t feat0 = (int64_t)y.L * y.dirs * p.max_T * tape_step_floats(y.H);
+    float s = 0.0f;
+    if (idx < y.C * y.F) {
+        const int q = idx / y.F, f = idx - q * y.F;
+        for (int tile = 0; tile < p.n_tiles; ++tile) {
+            const float* feat = p.tape + (int64_t)tile * p.tape_tile + feat0 + f * 32;
+            for (int c = 0; c < 32; ++c) {
+                const int o = p.order[tile * SNN_TILE + c];
+                if (o >= 0) s = fmaf(p.dlogits[(int64_t)o * y.C + q], feat[c], s);
+            }
+        }
+        float* dst = p.dflat + y.c_head_w + idx;
+        *dst = (p.accumulate ? *dst : 0.0f) + s;
+    } else {
+        const int q = idx - y.C * y.F;
+        for (int o = 0; o < p.n_curves; ++o) s += p.dlogits[(int64_t)o * y.C + q];
+        float* dst = p.dflat + y.c_head_b + q;
+        *dst = (p.accumulate ? *dst : 0.0f) + s;
+    }
+}
+
+// ---- the recurrent part ------------------------------------------------------------------------------
+template <int H>
+__global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int l)
+{
+    constexpr int MT = H / 32;          // output tiles of dh
+    constexpr int KSPLIT = 4 / MT;      // waves sharing one output tile (split over the gate rows)
+    constexpr int KW = 2 * H / KSPLIT;  // MFMA k-steps per wave
+    constexpr int UPT = H / 8;          // hidden units per thread in the element-wise stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dGl = smem;                  // [4H][32]  gate gradients of the running step (B operand image)
+    float* red = dGl + 4 * H * 32;      // [KSPLIT][H][32]
+    const SnnLayout& y = p.lay;
+    const int dirs = y.dirs;
+    const int tile = blockIdx.x / dirs, d = blockIdx.x - tile * dirs;
+    const int ld = l * dirs + d;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
+    const int T = p.tile_T[tile];
+    const bool last_layer = l == y.L - 1;
+    const int c = tid & 31, jg = tid >> 5;
+    const int len = p.len_sorted[tile * SNN_TILE + c];
+    const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+    const int64_t ts = tape_step_floats(H);
+    const float* tape_ld = p.tape + (int64_t)tile * p.tape_tile + (int64_t)ld * p.max_T * ts;
+    const float* dfeat = p.dfeat + (int64_t)tile * y.F * 32;
+    const float* dy = last_layer ? nullptr : p.dy_in + ((int64_t)tile * dirs + d) * p.max_T * H * 32;
+    float* dGg = p.dG + ((int64_t)tile * dirs + d) * p.max_T * 4 * H * 32;
+
+    const int mt = w / KSPLIT, ks = w - mt * KSPLIT;
+    float wT[KW];
+    {
+        const float* A = p.WT + p.wt_hh[ld] + ((int64_t)mt * 2 * H + ks * KW) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) wT[kk] = A[kk * 64];
+    }
+    float dc[UPT], dhr[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const int j = jg + 8 * i;
+        dc[i] = 0.0f;
+        dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * dirs) + ld) * 32 + c] : 0.0f;
+    }
+
+    for (int sb = 0; sb < T; ++sb) {
+        const int step = T - 1 - sb;
+        const int t = d == 0 ? step : T - 1 - step;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        const bool valid = t < len;
+        const bool prev_live = step > 0 && tp < len;
+        const float* tq = tape_ld + (int64_t)t * ts;
+        const float* tqp = tape_ld + (int64_t)tp * ts;
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int j = jg + 8 * i;
+            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+            if (valid) {
+                float dh = dhr[i];
+                if (dy) dh += dy[(int64_t)t * H * 32 + j * 32 + c];
+                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfeat[(d * H + j) * 32 + c] * inv_len;
+                const float ig = tq[(0 * H + j) * 32 + c], fg = tq[(1 * H + j) * 32 + c], gg = tq[(2 * H + j) * 32 + c];
+                const float og = tq[(3 * H + j) * 32 + c], cn = tq[(4 * H + j) * 32 + c];
+                const float cp = prev_live ? tqp[(4 * H + j) * 32 + c] : 0.0f;
+                const float tc = snn_tanh(cn);
+                const float dct = dc[i] + dh * og * (1.0f - tc * tc);
+                dao = dh * tc * og * (1.0f - og);
+                dai = dct * gg * ig * (1.0f - ig);
+                daf = dct * cp * fg * (1.0f - fg);
+                dag = dct * ig * (1.0f - gg * gg);
+                dc[i] = dct * fg;
+            }
+            dGl[(0 * H + j) * 32 + c] = dai;
+            dGl[(1 * H + j) * 32 + c] = daf;
+            dGl[(2 * H + j) * 32 + c] = dag;
+            dGl[(3 * H + j) * 32 + c] = dao;
+            float* o = dGg + (int64_t)t * 4 * H * 32 + j * 32 + c;
+            o[0 * H * 32] = dai;
+            o[1 * H * 32] = daf;
+            o[2 * H * 32] = dag;
+            o[3 * H * 32] = dao;
+        }
+        __syncthreads();
+        // dh_{prev}[j'][curve] = sum_R W_hh[R][j'] dG[R][curve]: this wave's output tile mt, gate rows of split ks
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            const float* b = dGl + (int64_t)ks * KW * 64 + lane;   // row 2kk + hf, column cl  ==  kk * 64 + lane
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[kk], b[kk * 64], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                red[((ks * H) + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hf) * 32 + cl] = acc[i];
+        }
+        __syncthreads();
+        if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int j = jg + 8 * i;
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) s += red[(k * H + j) * 32 + c];
+                dhr[i] = s;
+            }
+        }
+    }
+}
+
+// ---- dy of the layer below ------------------------------------------------------------------------------
+template <int H>
+__global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, int n_tchunks)
+{
+    constexpr int TS = 4;   // time steps per workgroup: every W_ih^T operand load feeds TS MFMAs
+    const SnnLayout& y = p.lay;
+    const int dirs = y.dirs;
+    const int tile = blockIdx.x / n_tchunks, t0 = (blockIdx.x - tile * n_tchunks) * TS;
+    const int T = p.tile_T[tile];
+    if (t0 >= T) return;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
+    const int MTX = dirs * H / 32;
+    const int orig = p.order[tile * SNN_TILE + cl];
+    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    for (int mt = w; mt < MTX; mt += 4) {
+        f32x16 acc[TS];
+#pragma unroll
+        for (int s = 0; s < TS; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
+        for (int d = 0; d < dirs; ++d) {
+            const int ld = l * dirs + d;
+            const float* A = p.WT + p.wt_ih[ld] + (int64_t)mt * 2 * H * 64 + lane;
+            const float* B = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t0) * 4 * H * 32 + lane;
+#pragma unroll 4
+            for (int kk = 0; kk < 2 * H; ++kk) {
+                const float a = A[kk * 64];
+#pragma unroll
+                for (int s = 0; s < TS; ++s)
+                    if (t0 + s < T) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[(int64_t)s * 4 * H * 32 + kk * 64], acc[s], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int t = t0 + s;
+            if (t >= T) break;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                float v = acc[s][i];
+                if (masked && orig >= 0) v = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, orig, f), v);
+                const int dd = f / H, j = f - dd * H;
+                p.dy_out[(((int64_t)tile * dirs + dd) * p.max_T + t) * H * 32 + j * 32 + cl] = v;
+            }
+        }
+    }
+}
+
+// ---- weight gradients -----------------------------------------------------------------------------------
+template <int H, int NTN_MAX>
+__global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int l, int n_chunks)
+{
+    constexpr int MG = 4 * H / 128;   // groups of 128 gate rows (one 32-row tile per wave)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dGs = smem;                // [128][PAD]
+    float* xhs = dGs + 128 * PAD;     // [NTN*32][PAD]: rows h_prev (H), x_t (I), ones (1), zero padding
+    const SnnLayout& y = p.lay;
+    const int dirs = y.dirs;
+    int b = blockIdx.x;
+    const int chunk = b % n_chunks; b /= n_chunks;
+    const int mg = b % MG, d = b / MG;
+    const int ld = l * dirs + d;
+    const int I = y.I[l], NCOL = H + I + 1, NTN = (NCOL + 31) / 32;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
+    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    const int64_t ts = tape_step_floats(H);
+    f32x16 acc[NTN_MAX];
+#pragma unroll
+    for (int nt = 0; nt < NTN_MAX; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+
+    const int64_t total = (int64_t)p.n_tiles * p.max_T, per = (total + n_chunks - 1) / n_chunks;
+    const int64_t p0 = chunk * per, p1 = std::min<int64_t>(total, p0 + per);
+    for (int64_t pp = p0; pp < p1; ++pp) {
+        const int tile = (int)(pp / p.max_T), t = (int)(pp - (int64_t)tile * p.max_T);
+        const int T = p.tile_T[tile];
+        if (t >= T) continue;
+        const float* tape = p.tape + (int64_t)tile * p.tape_tile;
+        // stage dG rows [128 mg, 128 mg + 128)
+        {
+            const float* src = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t) * 4 * H * 32 + (int64_t)mg * 128 * 32;
+            for (int f = tid; f < 128 * 8; f += 256) {
+                const int row = f >> 3, c4 = (f & 7) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * 32 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dGs[row * PAD + c4 + e] = v[e];
+            }
+        }
+        // stage [h_prev | x_t | 1 | 0...]
+        {
+            const int tp = d == 0 ? t - 1 : t + 1;
+            const bool first = d == 0 ? t == 0 : t == T - 1;   // first processed step of this direction: h_prev = 0
+            const float* xtile = p.xp + p.tile_off[tile];
+            for (int f = tid; f < NTN * 32 * 8; f += 256) {
+                const int row = f >> 3, c4 = (f & 7) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < H) {
+                    if (!first) v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32 + row * 32 + c4);
+                } else if (row < H + I) {
+                    const int k = row - H;
+                    if (l == 0) {
+                        v = *reinterpret_cast<const f32x4*>(xtile + ((int64_t)t * y.Dp + k) * 32 + c4);
+                        if (masked) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int o = p.order[tile * SNN_TILE + c4 + e];
+                                if (o >= 0) v[e] = __fmul_rn(mask_in(p.mk, 0, p.n_curves, y.D, o, k), v[e]);
+                            }
+                        }
+                    } else {
+                        const int dd = k / H, kk = k - dd * H;
+                        v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)((l - 1) * dirs + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + c4);
+                        if (masked) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int o = p.order[tile * SNN_TILE + c4 + e];
+                                if (o >= 0) v[e] = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
+                            }
+                        }
+                    }
+                } else if (row == H + I) {
+                    v = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = v[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a = dGs[(32 * w + cl) * PAD + 2 * kk + hf];
+#pragma unroll
+            for (int nt = 0; nt < NTN_MAX; ++nt)
+                if (nt < NTN) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhs[(32 * nt + cl) * PAD + 2 * kk + hf], acc[nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* slab = p.slabs + (int64_t)chunk * y.P;
+#pragma unroll
+    for (int nt = 0; nt < NTN_MAX; ++nt) {
+        if (nt >= NTN) break;
+        const int col = 32 * nt + cl;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int R = 128 * mg + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            const float v = acc[nt][i];
+            if (col < H) {
+                const float m = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
+                slab[y.c_whh[ld] + (int64_t)R * H + col] = m * v;
+            } else if (col - H < I) {
+                slab[y.c_wih[ld] + (int64_t)R * I + (col - H)] = v;
+            } else if (col == H + I) {
+                slab[y.c_bih[ld] + R] = v;
+                slab[y.c_bhh[ld] + R] = v;
+            }
+        }
+    }
+}
+
+// dflat[i] (+)= sum over chunks, fixed order; LSTM parameters only (the head is written by head_dw_kernel)
+__global__ void __launch_bounds__(256) chunk_reduce_kernel(int64_t n, int64_t P, int n_chunks, const float* __restrict__ slabs,
+                                                          float* __restrict__ out, int accumulate)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.0f;
+    for (int k = 0; k < n_chunks; ++k) s += slabs[(int64_t)k * P + i];
+    out[i] = s;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct Bwd2Geom { int n_chunks; int64_t wt_floats, dfeat_floats, dG_floats, dy_floats, slab_floats, total_bytes; };
+
+static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, int64_t* wt_hh, int64_t* wt_ih)
+{
+    int64_t off = 0;
+    for (int ld = 0; ld < y.L * y.dirs; ++ld) {
+        const int l = ld / y.dirs;
+        if (wt_hh) wt_hh[ld] = off;
+        off += (int64_t)(y.H / 32) * 2 * y.H * 64;
+        if (wt_ih) wt_ih[ld] = off;
+        if (l > 0) off += (int64_t)(y.I[l] / 32) * 2 * y.H * 64;
+    }
+    g->wt_floats = off;
+    g->dfeat_floats = (int64_t)n_tiles * y.F * 32;
+    g->dG_floats = (int64_t)n_tiles * y.dirs * max_T * 4 * y.H * 32;
+    g->dy_floats = (int64_t)n_tiles * y.dirs * max_T * y.H * 32;
+    const int64_t total = (int64_t)n_tiles * max_T;
+    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, total / 8));
+    g->slab_floats = (int64_t)g->n_chunks * y.P;
+    g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
+}
+
+bool snn_bwd_big_supported(const SnnLayout& y) { return (y.H == 64 || y.H == 128) && y.D <= SNN_MAX_D; }
+
+int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
+{
+    Bwd2Geom g;
+    bwd2_geom(y, n_tiles, max_T, &g, nullptr, nullptr);
+    return g.total_bytes;
+}
+
+template <int H>
+static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
+{
+    Bwd2Params p = p0;
+    const SnnLayout& y = p.lay;
+    const int n_ld = y.L * y.dirs;
+    hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dw_kernel, dim3((y.C * y.F + y.C + 255) / 256), dim3(256), 0, st, p);
+    HIP_CHECK(hipGetLastError());
+    constexpr int KSPLIT = 4 / (H / 32);
+    const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);
+    HIP_CHECK(hipFuncSetAttribute((const void*)bwd_rec_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec));
+    constexpr int NTN_MAX = (H + 2 * H + 1 + 31) / 32;   // widest layer: I = 2H (or D <= 78 <= 2H for H >= 64)
+    float* dyA = p.dfeat + g.dfeat_floats + g.dG_floats;
+    float* dyB = dyA + g.dy_floats;
+    for (int l = y.L - 1; l >= 0; --l) {
+        p.dy_in = (l & 1) ? dyA : dyB;    // written by the layer above
+        p.dy_out = (l & 1) ? dyB : dyA;
+        hipLaunchKernelGGL(bwd_rec_kernel<H>, dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
+        HIP_CHECK(hipGetLastError());
+        if (l > 0) {
+            const int n_tchunks = (p.max_T + 3) / 4;
+            hipLaunchKernelGGL(bwd_dx_kernel<H>, dim3(p.n_tiles * n_tchunks), dim3(256), 0, st, p, l, n_tchunks);
+            HIP_CHECK(hipGetLastError());
+        }
+        const int ntn = (H + y.I[l] + 1 + 31) / 32;
+        const size_t lds_dw = sizeof(float) * ((size_t)128 * PAD + (size_t)ntn * 32 * PAD);
+        HIP_CHECK(hipFuncSetAttribute((const void*)bwd_dw_kernel<H, NTN_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+        hipLaunchKernelGGL((bwd_dw_kernel<H, NTN_MAX>), dim3(y.dirs * (4 * H / 128) * g.n_chunks), dim3(256), lds_dw, st, p, l, g.n_chunks);
+        HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y.c_head_w, y.P,
+                       g.n_chunks, p.slabs, p.dflat, p.accumulate);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
+}
+
+int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
+                          const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles, int32_t max_T,
+                          const float* wk, const MaskP& mk, const float* tape, int64_t tape_tile, const float* dlogits,
+                          float* dflat, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    Bwd2Params p;
+    memset(&p, 0, sizeof(p));
+    Bwd2Geom g;
+    bwd2_geom(y, n_tiles, max_T, &g, p.wt_hh, p.wt_ih);
+    if (workspace_bytes < g.total_bytes) {
+        snn_set_error("snn_lstm_backward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.total_bytes);
+        return SNN_ERR_WORKSPACE;
+    }
+    p.lay = y;
+    p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
+    p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.wk = wk; p.mk = mk;
+    p.tape = tape; p.tape_tile = tape_tile; p.dlogits = dlogits;
+    p.WT = (float*)workspace;
+    p.dfeat = p.WT + g.wt_floats;
+    p.dG = p.dfeat + g.dfeat_floats;
+    p.slabs = p.dG + g.dG_floats + 2 * g.dy_floats;
+    p.dflat = dflat;
+    p.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    if (y.H == 128) return launch_big<128>(p, g, st);
+    if (y.H == 64) return launch_big<64>(p, g, st);
+    snn_set_error("no backward kernel for H=%d", y.H);
+    return SNN_ERR_UNSUPPORTED;
+}
