@@ -43,6 +43,11 @@ def main():
     ap.add_argument("--model", default="bayesian", choices=["bayesian", "variational", "vanilla"])
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"])
     ap.add_argument("--cpu-steps", type=int, default=20, help="train steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--features", type=int, default=24, help="input width D (24: 4 filters; 78: 6 filters + redshift)")
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--max-len", type=int, default=40)
+    ap.add_argument("--full-length", action="store_true", help="every curve has max-len steps (configs[4]: 300)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,20 +60,24 @@ def main():
     from supernnova_amd.utils import training_utils as tu
     D.init_from_env("nccl", dev)
 
-    st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0)
+    st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0,
+                  hidden_dim=args.hidden, nb_classes=args.classes)
+    Dw = args.features
     torch.manual_seed(0)                       # identical init and identical Philox seeds on every rank
-    rnn = tu.get_model(st, 24).to(dev)
+    rnn = tu.get_model(st, Dw).to(dev)
     D.broadcast_parameters(rnn)
     rnn.dp_curve_base = rank * args.batch
     opt = tu.get_optimizer(st, rnn)
     g = np.random.default_rng(100 + rank)
-    B, T = args.batch, 40
+    B, T = args.batch, args.max_len
     lengths = np.sort(g.integers(3, T + 1, size=B))[::-1].copy()
-    x = g.standard_normal((int(lengths[0]), B, 24)).astype(np.float32)
+    if args.full_length:
+        lengths[:] = T
+    x = g.standard_normal((int(lengths[0]), B, Dw)).astype(np.float32)
     for b in range(B):
         x[lengths[b]:, b] = 0
     packed = pack_padded_sequence(torch.from_numpy(x).to(dev), torch.from_numpy(lengths.astype(np.int64)))
-    target = torch.from_numpy(g.integers(0, 2, size=B)).to(dev)
+    target = torch.from_numpy(g.integers(0, args.classes, size=B)).to(dev)
     crit = torch.nn.CrossEntropyLoss()
     nb, gB = 100, B * world
 
@@ -101,7 +110,8 @@ def main():
                "value": gB * args.steps / dt, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{args.model} LSTM 32x2 bidirectional D=24 C=2, batch {B} per GPU, lengths U{{3..40}}, "
+               "config": {"workload": f"{args.model} LSTM {args.hidden}x2 bidirectional D={Dw} C={args.classes}, batch {B} per GPU, "
+                                      + (f"{T}-step sequences, " if args.full_length else f"lengths U{{3..{T}}}, ") +
                                       f"path={args.path}", "global_batch": gB, "parallelism": f"dp{world}"}}
         if args.cpu_steps > 0 and world == 1:
             from oracle import torch_port as tp
@@ -112,7 +122,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(args.cpu_steps):
                 copt.zero_grad()
-                l, _ = tp.train_loss(args.model, sd, pk, tg, B, nb)
+                l, _ = tp.train_loss(args.model, sd, pk, tg, B, nb, hidden=args.hidden)
                 l.backward()
                 copt.step()
             cdt = time.perf_counter() - t0

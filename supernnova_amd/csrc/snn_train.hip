@@ -7,6 +7,7 @@
 // (utils/training_utils.py:523-524) for the three model classes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 
@@ -41,6 +42,18 @@ static const BwdEntry* find_bwd(const SnnLayout& y)
 {
     return y.H == 32 ? snn_bwd_small_h32(y.KKI[0], y.dirs) : nullptr;
 }
+// H = 32 has both paths.  Measured on MI355X (BayesianRNN train step, lengths U{3..40}): batch 128 / 512 / 1024 /
+// 2048 / 4096 -> fused 1.58 / 1.59 / 1.60 / 1.62 / 1.73 ms, split 1.07 / 1.15 / 1.34 / 1.67 / 2.51 ms: the split
+// path runs both directions and the weight-gradient GEMMs in parallel (latency), the fused one keeps dG on chip
+// (throughput).  SNN_BWD_PATH=fused|split overrides (A/B measurements).
+static bool use_split_path(const SnnLayout& y, const BwdEntry* fused, int n_tiles)
+{
+    if (!fused) return true;
+    static const char* force = getenv("SNN_BWD_PATH");
+    if (force && force[0] == 'f') return false;
+    if (force && force[0] == 's') return true;
+    return n_tiles <= 48;
+}
 // H = 64, 128: recurrent kernel + deferred GEMMs (snn_train_big.hip)
 bool snn_bwd_big_supported(const SnnLayout& y);
 int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T);
@@ -64,7 +77,8 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
-    if (!find_bwd(y)) {
+    const BwdEntry* fused = find_bwd(y);
+    if (use_split_path(y, fused, n_tiles)) {
         if (snn_bwd_big_supported(y)) return snn_bwd_big_workspace_bytes(y, n_tiles, max_T);
         snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs);
         return SNN_ERR_UNSUPPORTED;
@@ -94,7 +108,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     }
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (tape_floats < tape_tile * n_tiles) { snn_set_error("snn_lstm_backward: tape too small"); return SNN_ERR_ARG; }
-    if (!e) {
+    if (use_split_path(y, e, n_tiles)) {
         MaskP mk;
         rc = snn_masks_to_device(masks, max_T, &mk);
         if (rc) return rc;

@@ -258,18 +258,27 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
             const int ld = l * dirs + d;
             const float* A = p.WT + p.wt_ih[ld] + (int64_t)mt * 2 * H * 64 + lane;
             const float* B = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t0) * 4 * H * 32 + lane;
-#pragma unroll 4
-            for (int kk = 0; kk < 2 * H; ++kk) {
-                const float a = A[kk * 64];
+            // operands stream from L2: issue a batch of KB k-steps' loads, then their MFMAs (steps beyond the
+            // tile's last one read the next step's rows of the same buffer and are never stored)
+            constexpr int KB = 16;
+            for (int k0 = 0; k0 < 2 * H; k0 += KB) {
+                float a[KB], b[TS][KB];
 #pragma unroll
-                for (int s = 0; s < TS; ++s)
-                    if (t0 + s < T) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B[(int64_t)s * 4 * H * 32 + kk * 64], acc[s], 0, 0, 0);
+                for (int k = 0; k < KB; ++k) {
+                    a[k] = A[(k0 + k) * 64];
+#pragma unroll
+                    for (int s = 0; s < TS; ++s) b[s][k] = (t0 + s < p.max_T) ? B[(int64_t)s * 4 * H * 32 + (k0 + k) * 64] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+#pragma unroll
+                    for (int s = 0; s < TS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[s][k], acc[s], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const int t = t0 + s;
-            if (t >= T) break;
+            if (t < T) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int f = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hf;
@@ -277,6 +286,7 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
                 if (masked && orig >= 0) v = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, orig, f), v);
                 const int dd = f / H, j = f - dd * H;
                 p.dy_out[(((int64_t)tile * dirs + dd) * p.max_T + t) * H * 32 + j * 32 + cl] = v;
+            }
             }
         }
     }
@@ -375,9 +385,8 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
 
     float* slab = p.slabs + (int64_t)chunk * y.P;
 #pragma unroll
-    for (int nt = 0; nt < NTN_MAX; ++nt) {
-        if (nt >= NTN) break;
-        const int col = 32 * nt + cl;
+    for (int nt = 0; nt < NTN_MAX; ++nt) {   // (no early exit: acc[] must stay in registers, i.e. constant-indexed)
+        const int col = nt < NTN ? 32 * nt + cl : H + I + 1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int R = 128 * mg + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
@@ -429,7 +438,7 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
 }
 
-bool snn_bwd_big_supported(const SnnLayout& y) { return (y.H == 64 || y.H == 128) && y.D <= SNN_MAX_D; }
+bool snn_bwd_big_supported(const SnnLayout& y) { return (y.H == 32 || y.H == 64 || y.H == 128) && y.D <= SNN_MAX_D; }
 
 int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
 {
@@ -502,6 +511,7 @@ int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* le
     hipStream_t st = (hipStream_t)stream;
     if (y.H == 128) return launch_big<128>(p, g, st);
     if (y.H == 64) return launch_big<64>(p, g, st);
+    if (y.H == 32) return launch_big<32>(p, g, st);
     snn_set_error("no backward kernel for H=%d", y.H);
     return SNN_ERR_UNSUPPORTED;
 }

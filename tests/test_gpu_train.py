@@ -183,23 +183,30 @@ def test_adam_kernel_matches_reference_update(model):
     np.testing.assert_allclose(p.cpu().numpy(), flat(g["sd1"], keys), atol=1e-7, rtol=0)
 
 
-@pytest.mark.parametrize("D,H,L,bidir,pool,C", [(24, 32, 2, True, "mean", 2), (42, 32, 2, True, "mean", 3),
+def _shape_cases(cases):
+    return [c if len(c) == 7 else c + (50,) for c in cases]
+
+
+@pytest.mark.parametrize("D,H,L,bidir,pool,C,N", _shape_cases([(24, 32, 2, True, "mean", 2), (42, 32, 2, True, "mean", 3),
                                                 (78, 32, 2, True, "standard", 5), (24, 64, 2, True, "mean", 2),
                                                 (78, 64, 2, True, "mean", 14), (26, 32, 1, True, "mean", 2),
                                                 (24, 32, 3, True, "standard", 2), (44, 32, 2, False, "mean", 2),
                                                 (24, 64, 2, False, "standard", 3), (78, 128, 2, True, "mean", 14),
                                                 (24, 128, 2, True, "standard", 3), (42, 128, 1, True, "mean", 2),
-                                                (24, 128, 2, False, "mean", 2), (24, 64, 3, True, "mean", 2)])
-def test_backward_shapes_vs_autograd(D, H, L, bidir, pool, C):
+                                                (24, 128, 2, False, "mean", 2), (24, 64, 3, True, "mean", 2),
+                                                (24, 32, 2, True, "mean", 2, 1700), (26, 32, 2, True, "standard", 3, 1601)]))
+def test_backward_shapes_vs_autograd(D, H, L, bidir, pool, C, N):
     """Gradients of CE(logits, target) w.r.t. every weight, for shapes beyond the reference fixtures, against
-    autograd through the stock-PyTorch port (aten::lstm on the CPU: what the reference differentiates)."""
+    autograd through the stock-PyTorch port (aten::lstm on the CPU: what the reference differentiates).
+    H = 32 has two backward paths: up to 48 tiles the split one (recurrent kernel + deferred GEMMs), beyond
+    that the fused kernel -- the N > 1536 cases."""
     from supernnova_amd import engine as E
     from oracle import torch_port as tp
     from util import make_curves
     dirs = 2 if bidir else 1
     cfg = E.Config(D, H, L, bidir, C, pool)
     g = np.random.default_rng(61)
-    N, T = 50, 13
+    T = 13
     x, lengths = make_curves(62, N, T, D, min_len=1)
     order = np.argsort(-lengths, kind="stable")
     x, lengths = np.ascontiguousarray(x[:, order]), lengths[order]
