@@ -216,7 +216,7 @@ def main():
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
                        "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": "lstm_fwd_big_kernel<128,39,2>" if big else "lstm_fwd_kernel<32,12,2,false,false>", "achieved": achieved,
+                         "kernel": "lstm_fwd_big_kernel<128,39,2,false>" if big else "lstm_fwd_pair_kernel<32,12,2>", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": k_ms, "flop_per_launch": fl},
