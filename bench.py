@@ -121,6 +121,9 @@ def main():
                     help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
                          "(H=128, 6 filters + redshift, 14 classes, 300-step sequences) -- a secondary measurement")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+                    help="f32: every gate product in fp32 (default); bf16x3: each fp32 product rebuilt from six bf16 "
+                         "piece products on the bf16 matrix pipe (fp32-equivalent accuracy, include/snn_hip.h)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +148,7 @@ def main():
             args.max_len = 300
     else:
         cfg = E.Config(24, 32, 2, True, 2, "mean")
+    cfg = cfg.with_precision(args.precision)
     S, N = args.samples, args.curves
     mu, rho = bayes_init(cfg, 0, dev)
     x, lengths = synth_curves(N, args.max_len, 6 if big else 4, dev, seed=1000 + rank, redshift=big)

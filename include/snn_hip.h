@@ -56,7 +56,22 @@ typedef struct snn_cfg {
     int32_t bidirectional; /* 0/1 */
     int32_t nb_classes;    /* C  */
     int32_t pool;          /* SNN_POOL_* */
+    int32_t precision;     /* SNN_PREC_*: arithmetic of the gate products in snn_lstm_forward */
 } snn_cfg;
+
+/*
+ * SNN_PREC_F32     every product in fp32 (v_mfma_f32_32x32x2_f32): the default, and the only mode of the
+ *                  training entry points.
+ * SNN_PREC_BF16X3  inference only: x, h and W are cut into 3 bf16 pieces each (hi + mid + lo = the fp32 value
+ *                  to 2^-27) and every fp32 product is rebuilt from 6 bf16 products accumulated in fp32
+ *                  (v_mfma_f32_32x32x16_bf16; the dropped cross terms are below 2^-24 relative, i.e. below fp32
+ *                  rounding).  Same parity bar; different rounding order.  The packed x image and the weight
+ *                  image have a different size and layout in this mode: snn_x_step_floats / snn_kparam_count
+ *                  report it, and snn_pack_x, snn_prepare_weights, snn_bbb_sample and snn_lstm_forward must all
+ *                  be called with the same precision.
+ */
+#define SNN_PREC_F32 0
+#define SNN_PREC_BF16X3 1
 
 /* Prior of training/bayesian_rnn.py:753-763 (LSTM prior, then the head's). */
 typedef struct snn_prior {
@@ -103,6 +118,7 @@ int64_t snn_param_count(const snn_cfg *cfg);  /* P: canonical flat floats incl. 
 int64_t snn_kparam_count(const snn_cfg *cfg); /* PK: floats of ONE weight set in kernel layout        */
 int32_t snn_feat(const snn_cfg *cfg);         /* F */
 int snn_supported(const snn_cfg *cfg);        /* 1 if this build has forward kernels for cfg          */
+int64_t snn_x_step_floats(const snn_cfg *cfg); /* 4-byte words of ONE time step of ONE tile in the packed x image */
 
 /*
  * Host-side batching plan; replaces the sort/pad bookkeeping of
@@ -113,8 +129,10 @@ int snn_supported(const snn_cfg *cfg);        /* 1 if this build has forward ker
  *   order      (n_tiles*32) sorted position -> original index (-1 = padding)
  *   len_sorted (n_tiles*32) length at sorted position (0 = padding)
  *   tile_T     (n_tiles)
- *   tile_off   (n_tiles+1)  float offset of each tile in the packed x buffer
- *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D padded to the next supported width: 24, 26, 48, 76 or 78)
+ *   tile_off   (n_tiles+1)  float offset of each tile in the fp32 packed x buffer
+ *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D padded to the next supported width:
+ *                           24, 26, 48, 76 or 78); tile_off[n_tiles] / (Dp*32) is the total number of tile-steps,
+ *                           and the packed buffer holds that many times snn_x_step_floats(cfg) words
  * n_tiles = ceil(n_curves/32).  Lengths must be >= 1.
  */
 int snn_plan_build(const snn_cfg *cfg, const int32_t *lengths_host, int32_t n_curves,

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # env override: A/B builds
 
 SNN_POOL_MEAN, SNN_POOL_STANDARD = 0, 1
+SNN_PREC_F32, SNN_PREC_BF16X3 = 0, 1
 SNN_MASK_NONE, SNN_MASK_ARRAYS, SNN_MASK_PHILOX = 0, 1, 2
 BBB_EPS, BBB_MFE, BBB_PHILOX = 0, 1, 2
 TILE = 32
@@ -19,7 +20,7 @@ TILE = 32
 class SnnCfg(ctypes.Structure):
     _fields_ = [("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
                 ("num_layers", ctypes.c_int32), ("bidirectional", ctypes.c_int32),
-                ("nb_classes", ctypes.c_int32), ("pool", ctypes.c_int32)]
+                ("nb_classes", ctypes.c_int32), ("pool", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
 class SnnPrior(ctypes.Structure):
@@ -53,6 +54,7 @@ SIGNATURES = {
     "snn_kparam_count": (ctypes.c_int64, [_CFG]),
     "snn_feat": (ctypes.c_int32, [_CFG]),
     "snn_supported": (ctypes.c_int, [_CFG]),
+    "snn_x_step_floats": (ctypes.c_int64, [_CFG]),
     "snn_plan_build": (ctypes.c_int, [_CFG, _I32P, ctypes.c_int32, _I32P, _I32P, _I32P, _I64P]),
     "snn_pack_x": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P,
                                   ctypes.c_int32, ctypes.c_int64, _P, _P]),

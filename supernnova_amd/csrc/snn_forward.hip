@@ -19,6 +19,41 @@
 // ============================================================================
 // pack_x: one workgroup per tile, one thread per (t, curve), loop over features
 // ============================================================================
+// precision 1: xp3[tile][t][XB][3 pieces][64 lanes][8 bf16], lane (curve = lane & 31, khalf = lane >> 5) holds features
+// 16 b + 8 khalf + e -- the B operand of v_mfma_f32_32x32x16_bf16, three times (hi, mid, lo)
+__global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, const float* __restrict__ x,
+                                                     int64_t stride_t, int64_t stride_n,
+                                                     const int64_t* __restrict__ curve_off,
+                                                     const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ len_sorted,
+                                                     const int32_t* __restrict__ tile_T,
+                                                     const int64_t* __restrict__ tile_off,
+                                                     __bf16* __restrict__ xp)
+{
+    const int tile = blockIdx.x;
+    const int T = tile_T[tile];
+    const int64_t step_bf16 = (int64_t)XB * 3 * 64 * 8;
+    __bf16* dst = xp + tile_off[tile] / ((int64_t)Dp * SNN_TILE) * step_bf16;
+    for (int idx = threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x) {
+        const int t = idx >> 5, c = idx & 31;
+        const int pos = tile * SNN_TILE + c;
+        const int orig = order[pos];
+        const bool live = orig >= 0 && t < len_sorted[pos];
+        const int on = live ? orig : 0;
+        const float* src = x + (int64_t)t * stride_t + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
+        __bf16* o = dst + (int64_t)t * step_bf16;
+        for (int k = 0; k < 16 * XB; ++k) {
+            const float v = (live && k < D) ? src[k] : 0.0f;
+            __bf16 h, m, l;
+            split3(v, h, m, l);
+            const int64_t a = ((((int64_t)(k >> 4) * 3) * 64) + ((k >> 3) & 1) * 32 + c) * 8 + (k & 7);
+            o[a] = h;
+            o[a + 64 * 8] = m;
+            o[a + 2 * 64 * 8] = l;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float* __restrict__ x,
                                                     int64_t stride_t, int64_t stride_n,
                                                     const int64_t* __restrict__ curve_off,
@@ -100,7 +135,16 @@ __global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const floa
                 p2 += (double)(__fdiv_rn(-x2, 2.0f * v2) - l2 - lsq);
             }
         }
-        dst[kernel_index(y, g, i)] = w;
+        if (y.prec == 1 && g.kind <= 1) {
+            __bf16 wh, wm, wl;
+            split3(w, wh, wm, wl);
+            __bf16* d3 = reinterpret_cast<__bf16*>(dst) + kernel_index3(y, g, i);
+            d3[0] = wh;
+            d3[64 * 8] = wm;
+            d3[2 * 64 * 8] = wl;
+        } else {
+            dst[kernel_index(y, g, i)] = w;
+        }
     }
     if (kl_terms != nullptr && g.kind != 5) {
         q = block_sum(q, sh);
@@ -150,9 +194,9 @@ int snn_make_layout(const snn_cfg* cfg, SnnLayout* y)
 {
     if (!cfg) { snn_set_error("cfg is NULL"); return SNN_ERR_ARG; }
     if (snn_layout_init(y, cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->bidirectional,
-                        cfg->nb_classes, cfg->pool) != 0) {
-        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d (need H %% 8 == 0, 1 <= L <= %d)", cfg->input_size,
-                      cfg->hidden_size, cfg->num_layers, cfg->nb_classes, cfg->pool, SNN_MAX_LAYERS);
+                        cfg->nb_classes, cfg->pool, cfg->precision) != 0) {
+        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d precision=%d (need H %% 8 == 0, 1 <= L <= %d)", cfg->input_size,
+                      cfg->hidden_size, cfg->num_layers, cfg->nb_classes, cfg->pool, cfg->precision, SNN_MAX_LAYERS);
         return SNN_ERR_ARG;
     }
     return SNN_OK;
@@ -170,6 +214,13 @@ extern "C" int64_t snn_kparam_count(const snn_cfg* cfg)
     int rc = snn_make_layout(cfg, &y);
     return rc ? rc : y.PK;
 }
+extern "C" int64_t snn_x_step_floats(const snn_cfg* cfg)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    return y.prec == 1 ? (int64_t)y.XB[0] * 3 * 64 * 4 : (int64_t)y.Dp * SNN_TILE;
+}
 extern "C" int32_t snn_feat(const snn_cfg* cfg)
 {
     SnnLayout y;
@@ -185,9 +236,12 @@ const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
 fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pair.hip
+typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
+fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
 static const FwdEntry* find_fwd(const SnnLayout& y)
 {
     static thread_local FwdEntry ent;
+    if (y.prec != 0) return nullptr;   // the bf16 x 3 kernels have their own launcher
     const FwdSmallEntry* e = y.H == 32 ? snn_fwd_small_h32(y.KKI[0], y.dirs)
                            : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
     if (e) {
@@ -205,6 +259,7 @@ extern "C" int snn_supported(const snn_cfg* cfg)
 {
     SnnLayout y;
     if (snn_make_layout(cfg, &y)) return 0;
+    if (y.prec == 1) return snn_b3_kernel(y.H, y.XB[0], y.dirs) != nullptr;
     return find_fwd(y) != nullptr;
 }
 
@@ -265,6 +320,12 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
         return SNN_ERR_ARG;
     }
     (void)xp_floats;
+    if (y.prec == 1) {
+        hipLaunchKernelGGL(pack_x3_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t,
+                           stride_n, curve_off, order, len_sorted, tile_T, tile_off, reinterpret_cast<__bf16*>(xp));
+        HIP_CHECK(hipGetLastError());
+        return SNN_OK;
+    }
     hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
                        stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp);
     HIP_CHECK(hipGetLastError());
@@ -275,7 +336,7 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
                          float* kl_terms, hipStream_t st)
 {
-    if (y.PK != y.k_head_b + y.C || y.Dp != y.D)  // padding floats exist: define them
+    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec == 1)  // padding words exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
     hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
                        offset, prior, wk, kl ? kl_terms : nullptr);
@@ -357,11 +418,77 @@ static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, Fw
     return SNN_OK;
 }
 
+// ---- bf16 x 3 forward (SNN_PREC_BF16X3) ----------------------------------------------------------------
+static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g)
+{
+    const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
+    g->threads = y.H * 8;
+    g->lds = (size_t)(2 * XBM + 2 * HB) * 192 * 16 + sizeof(float) * ((size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
+    if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
+    int dev = 0, cus = 0, per_cu = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, g->threads, g->lds));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    g->grid = cus * per_cu;
+    g->cus = cus;
+    g->nbuf = y.L > 2 ? 2 : 1;
+    g->y_buf_floats = (int64_t)max_T * y.dirs * HB * 192 * 4;   // [t][dir * HB blocks][3 pieces][64 lanes][8 bf16]
+    g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
+    return SNN_OK;
+}
+
+static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
+                             const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles,
+                             int32_t max_T, const float* wk, int64_t wk_sample_stride, int32_t n_samples,
+                             float* out_logits, float* out_probs, int64_t out_stride_sample, int64_t out_stride_curve,
+                             void* workspace, int64_t workspace_bytes, void* stream)
+{
+    fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
+    if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    FwdGeom g;
+    int rc = b3_geom(y, fn, max_T, &g);
+    if (rc) return rc;
+    if (workspace_bytes < g.ws_bytes) {
+        snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
+        return SNN_ERR_WORKSPACE;
+    }
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.D = y.D; p.Dp = y.Dp; p.L = y.L; p.C = y.C; p.pool = y.pool; p.F = y.F;
+    p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
+    p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
+    p.wk = wk; p.wk_stride = wk_sample_stride;
+    p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
+    p.counter = (unsigned int*)workspace;
+    p.yscratch = (float*)((char*)workspace + 256);
+    p.y_buf_floats = g.y_buf_floats;
+    p.nbuf = g.nbuf;
+    B3Offsets o;
+    for (int ld = 0; ld < y.L * y.dirs; ++ld) { o.k_A[ld] = y.k_A[ld]; o.k_bias[ld] = y.k_bias[ld]; }
+    o.k_head_w = y.k_head_w;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
+    const int64_t n_items = (int64_t)n_tiles * n_samples;
+    hipLaunchKernelGGL(fn, dim3((int)std::min<int64_t>(g.grid, n_items)), dim3(g.threads), g.lds, st, p, o);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
+}
+
 extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t max_T)
 {
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if (y.prec == 1) {
+        fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
+        if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+        if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
+        FwdGeom g;
+        rc = b3_geom(y, fn, max_T, &g);
+        return rc ? rc : g.ws_bytes;
+    }
     const FwdEntry* e = find_fwd(y);
     if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
@@ -414,10 +541,14 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
     const FwdEntry* e = find_fwd(y);
-    if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (!e && y.prec == 0) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !workspace || (!out_logits && !out_probs)) {
         snn_set_error("snn_lstm_forward: null pointer");
         return SNN_ERR_ARG;
+    }
+    if (y.prec == 1 && (train || (masks && masks->mode != SNN_MASK_NONE))) {
+        snn_set_error("SNN_PREC_BF16X3 is implemented for un-masked inference only");
+        return SNN_ERR_UNSUPPORTED;
     }
     if (n_curves < 1 || n_tiles != (n_curves + SNN_TILE - 1) / SNN_TILE || max_T < 1 || n_samples < 1 ||
         (int64_t)n_tiles * n_samples > 0x7fffffff || wk_sample_stride < 0 ||
@@ -426,6 +557,10 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                       n_tiles, max_T, n_samples);
         return SNN_ERR_ARG;
     }
+    if (y.prec == 1)
+        return launch_forward_b3(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, wk_sample_stride,
+                                 n_samples, out_logits, out_probs, out_stride_sample, out_stride_curve, workspace,
+                                 workspace_bytes, stream);
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (train && (!tape || n_samples != 1 || tape_floats < tape_tile * n_tiles)) {
         snn_set_error("snn_lstm_forward_train: tape missing or too small (%lld < %lld floats) or n_samples != 1",
@@ -452,7 +587,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     FwdParams p;
     memset(&p, 0, sizeof(p));
-    p.D = y.D; p.L = y.L; p.C = y.C; p.pool = y.pool; p.F = y.F;
+    p.D = y.D; p.Dp = y.Dp; p.L = y.L; p.C = y.C; p.pool = y.pool; p.F = y.F;
     p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
     p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
     p.wk = wk; p.wk_stride = wk_sample_stride;

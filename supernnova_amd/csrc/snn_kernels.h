@@ -108,6 +108,27 @@ __device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const Tensor
     return y.k_bias[g.ld] + (g.kind == 3 ? y.NW * 32 : 0) + (w * 2 + hf) * 16 + ii;
 }
 
+// precision 1: index (in bf16 units from the start of the weight set) of piece 0 of canonical element i of a
+// weight matrix g (kind 0 / 1); piece p sits 64 * 8 * p further
+__device__ __forceinline__ int64_t kernel_index3(const SnnLayout& y, const TensorGeom& g, int64_t i)
+{
+    const int l = g.ld / y.dirs, H = y.H;
+    const int R = (int)(i / g.cols), col = (int)(i - (int64_t)R * g.cols);
+    const int gate = R / H, j = R - gate * H;
+    const int w = j >> 3, r = gate * 8 + (j & 7);
+    const int k = g.kind == 0 ? col : 16 * y.XB[l] + col;
+    const int b = k >> 4, lane = ((k >> 3) & 1) * 32 + r, e = k & 7;
+    return y.k_A[g.ld] * 2 + ((((int64_t)w * y.NB[l] + b) * 3) * 64 + lane) * 8 + e;
+}
+// x = hi + mid + lo to 2^-27 relative, each piece a bf16 (round-to-nearest-even; the two remainders are exact in fp32)
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
+{
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
 // LDS-only barrier: global stores of the step stay in flight (they are only
 // read after a later __syncthreads()).
 __device__ __forceinline__ void lds_barrier()
@@ -131,8 +152,11 @@ __host__ __device__ inline int64_t tape_tile_floats(int H, int n_ld, int max_T, 
 }
 
 // ---- forward kernel parameters (snn_forward.hip, snn_forward_big.hip) ---------
+// weight-image offsets of the bf16 x 3 forward kernel (4-byte words from the start of a weight set)
+struct B3Offsets { int64_t k_A[SNN_MAX_LD], k_bias[SNN_MAX_LD], k_head_w; };
+
 struct FwdParams {
-    int D, L, C, pool, F;
+    int D, Dp, L, C, pool, F;
     const float* xp;
     const int32_t* len_sorted;
     const int32_t* order;

@@ -35,6 +35,12 @@ struct SnnLayout {
     int64_t c_head_w, c_head_b, k_head_w, k_head_b;
     int64_t P, PK;
     int n_tensors;  // sampled tensors: 4*L*dirs + 1
+    // precision 1 (bf16 x 3 pieces, snn_forward_b3.hip): the A image of (layer, dir) is
+    //   [NW][NB][3 pieces][64 lanes][8 bf16]   lane (r = lane & 31, khalf = lane >> 5) holds
+    //   Wcat3[row(w, r)][16 b + 8 khalf + e], Wcat3 = [w_ih | zero pad to 16*XB | w_hh], NB = XB + H/16;
+    // k_A / k_bias / k_head_* / PK then describe that image (in 4-byte words); bias and head stay fp32.
+    int prec;
+    int XB[SNN_MAX_LAYERS], NB[SNN_MAX_LAYERS];
 };
 
 // MFMA k-steps of the layer-0 input part.  The kernels are instantiated for a few widths; an input size in
@@ -49,10 +55,12 @@ static inline int snn_kki0_bucket(int D)
     return (D + 1) / 2;
 }
 
-static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool)
+static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool, int prec = 0)
 {
-    if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1)
+    if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1 || prec < 0 ||
+        prec > 1 || (prec == 1 && (H % 16) != 0))
         return -1;
+    y->prec = prec;
     y->D = D; y->H = H; y->L = L; y->dirs = bidir ? 2 : 1; y->C = C; y->pool = pool;
     y->F = pool == 0 ? y->dirs * H : y->dirs * H * L;
     y->Dp = 2 * snn_kki0_bucket(D);
@@ -62,13 +70,15 @@ static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, 
         y->I[l] = l == 0 ? D : y->dirs * H;
         y->KKI[l] = l == 0 ? y->Dp / 2 : (y->I[l] + 1) / 2;
         y->KK[l] = y->KKI[l] + H / 2;
+        y->XB[l] = (2 * y->KKI[l] + 15) / 16;
+        y->NB[l] = y->XB[l] + H / 16;
         for (int d = 0; d < y->dirs; ++d) {
             int ld = l * y->dirs + d;
             y->c_wih[ld] = c; c += (int64_t)4 * H * y->I[l];
             y->c_whh[ld] = c; c += (int64_t)4 * H * H;
             y->c_bih[ld] = c; c += 4 * H;
             y->c_bhh[ld] = c; c += 4 * H;
-            y->k_A[ld] = k; k += (int64_t)y->NW * y->KK[l] * 64;
+            y->k_A[ld] = k; k += prec == 0 ? (int64_t)y->NW * y->KK[l] * 64 : (int64_t)y->NW * y->NB[l] * 3 * 64 * 4;
             y->k_bias[ld] = k; k += (int64_t)2 * y->NW * 32;
         }
     }

@@ -39,11 +39,21 @@ class Config:
     bidirectional: bool = True
     nb_classes: int = 2
     pool: str = "mean"
+    precision: str = "f32"      # "f32" | "bf16x3" (include/snn_hip.h: SNN_PREC_*; inference only)
 
     @property
     def c(self):
         return L.SnnCfg(self.input_size, self.hidden_size, self.num_layers, int(bool(self.bidirectional)),
-                        self.nb_classes, L.SNN_POOL_MEAN if self.pool == "mean" else L.SNN_POOL_STANDARD)
+                        self.nb_classes, L.SNN_POOL_MEAN if self.pool == "mean" else L.SNN_POOL_STANDARD,
+                        L.SNN_PREC_BF16X3 if self.precision == "bf16x3" else L.SNN_PREC_F32)
+
+    def with_precision(self, precision):
+        from dataclasses import replace
+        return replace(self, precision=precision)
+
+    @property
+    def x_step_floats(self):
+        return L.check(L.load().snn_x_step_floats(ctypes.byref(self.c)), "snn_x_step_floats")
 
     @property
     def dirs(self):
@@ -91,11 +101,16 @@ class Plan:
             self.tile_T.ctypes.data_as(i32), self.tile_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))),
             "snn_plan_build")
         self.max_T = int(self.tile_T[0])
-        self.xp_floats = int(self.tile_off[-1])
+        self.total_steps = int(self.tile_T.astype(np.int64).sum())
+        self.xp_floats = int(self.tile_off[-1])      # of the fp32 image; see packed_floats()
         self.lengths = lengths
         self.device = None
         if device is not None:
             self.to(device)
+
+    def packed_floats(self, cfg):
+        """4-byte words of the packed x image for cfg's precision."""
+        return self.total_steps * cfg.x_step_floats
 
     def to(self, device):
         self.device = torch.device(device)
@@ -116,10 +131,11 @@ def pack_x(cfg, plan, x, time_major=True):
         raise L.SnnError(f"x {tuple(x.shape)} does not match plan (n_curves={plan.n_curves}, max_T={plan.max_T})")
     D = cfg.input_size
     st, sn = (B * D, D) if time_major else (D, T * D)
-    xp = torch.empty(plan.xp_floats, dtype=torch.float32, device=x.device)
+    n_xp = plan.packed_floats(cfg)
+    xp = torch.empty(n_xp, dtype=torch.float32, device=x.device)
     L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(x), st, sn, None, _ptr(plan.d_order),
                                 _ptr(plan.d_len_sorted), _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles,
-                                plan.xp_floats, _ptr(xp), _stream()), "snn_pack_x")
+                                n_xp, _ptr(xp), _stream()), "snn_pack_x")
     return xp
 
 
@@ -134,10 +150,11 @@ def pack_ragged(cfg, plan, rows, curve_off):
         raise L.SnnError("curve_off must be a device int64 tensor with one entry per curve")
     if rows.size(0) != int(plan.lengths.astype(np.int64).sum()):
         raise L.SnnError("rows does not hold sum(lengths) rows")
-    xp = torch.empty(plan.xp_floats, dtype=torch.float32, device=rows.device)
+    n_xp = plan.packed_floats(cfg)
+    xp = torch.empty(n_xp, dtype=torch.float32, device=rows.device)
     L.check(L.load().snn_pack_x(ctypes.byref(cfg.c), _ptr(rows), D, 0, _ptr(curve_off), _ptr(plan.d_order),
                                 _ptr(plan.d_len_sorted), _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles,
-                                plan.xp_floats, _ptr(xp), _stream()), "snn_pack_x")
+                                n_xp, _ptr(xp), _stream()), "snn_pack_x")
     return xp
 
 
@@ -250,7 +267,7 @@ def lstm_forward(cfg, plan, xp, wk, n_samples, masks=None, want_logits=True, wan
         if wk.shape != (S, cfg.PK):
             raise L.SnnError(f"wk shape {tuple(wk.shape)} != ({S},{cfg.PK})")
         stride = cfg.PK
-    if xp.numel() != plan.xp_floats:
+    if xp.numel() != plan.packed_floats(cfg):
         raise L.SnnError("xp does not match the plan")
     shape = (S, N, C) if sample_major else (N, S, C)
     os_s, os_n = (N * C, C) if sample_major else (C, S * C)

@@ -78,6 +78,17 @@ class _HipRNN(nn.Module):
     """Shared host logic: input unpacking, plan/pack, launch."""
 
     draws = "philox"
+    # arithmetic of the gate products in eval-mode forwards without dropout masks (VanillaRNN, BayesianRNN):
+    # "f32" (exact fp32, default) or "bf16x3" (six bf16 piece products per fp32 product; include/snn_hip.h)
+    inference_precision = "f32"
+
+    def infer_cfg(self, masked=False):
+        """Engine config of an inference launch: the module's cfg, in `inference_precision` when that mode has a
+        kernel for this shape and the launch carries no masks."""
+        if masked or self.inference_precision == "f32" or isinstance(self, VariationalRNN):
+            return self.cfg      # (VariationalRNN keeps one fp32 weight image for masked and mean-field launches)
+        cfg = self.cfg.with_precision(self.inference_precision)
+        return cfg if cfg.supported() else self.cfg
 
     def _init_common(self, input_size, settings):
         _check_settings(settings)
@@ -229,9 +240,10 @@ class _HipRNN(nn.Module):
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
-        plan = E.Plan(self.cfg, lengths, padded.device)
-        xp = E.pack_x(self.cfg, plan, padded)
-        return E.lstm_forward(self.cfg, plan, xp, wk, n_samples, masks=masks, want_logits=True,
+        cfg = self.infer_cfg(masks is not None)
+        plan = E.Plan(cfg, lengths, padded.device)
+        xp = E.pack_x(cfg, plan, padded)
+        return E.lstm_forward(cfg, plan, xp, wk, n_samples, masks=masks, want_logits=True,
                               want_probs=want_probs, sample_major=True), plan
 
 
@@ -262,17 +274,17 @@ class VanillaRNN(_HipRNN):
             fn = (lambda plan: masks) if masks is not None else self._masks
             logits, _ = self._train_forward(x, fn)
             return logits
-        wk = E.prepare_weights(self.cfg, self._flat("w"))
+        wk = E.prepare_weights(self.infer_cfg(masks is not None), self._flat("w"))
         (logits, _), _ = self._launch(x, wk, 1, masks)
         return logits[0]
 
     def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
         """(kernel-layout weights, masks) for n_samples forwards over n_curves curves."""
-        return E.prepare_weights(self.cfg, self._flat("w")), None
+        return E.prepare_weights(self.infer_cfg(), self._flat("w")), None
 
     def forward_mc(self, x, n_samples=1, mean_field_inference=False):
         """probs (B, n_samples, C); a vanilla model is deterministic in eval mode."""
-        wk = E.prepare_weights(self.cfg, self._flat("w"))
+        wk = E.prepare_weights(self.infer_cfg(), self._flat("w"))
         (_, probs), _ = self._launch(x, wk, n_samples, None, want_probs=True)
         return probs.permute(1, 0, 2)
 
@@ -438,7 +450,7 @@ class BayesianRNN(_HipRNN):
         seed = offset = 0
         if not mean_field_inference and eps is None:
             seed = self._seed()
-        return E.bbb_sample(self.cfg, mu, rho, n_samples, self._prior, eps=eps,
+        return E.bbb_sample(self.infer_cfg(), mu, rho, n_samples, self._prior, eps=eps,
                             mean_field=mean_field_inference, seed=seed, offset=offset)
 
     def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False, eps=None):

@@ -77,10 +77,10 @@ def predict_mc(rnn, curves, n_samples, mean_field_inference=False, lengths=None,
         rows, curve_off, lengths = curves
     else:
         rows, curve_off, lengths = ragged_to_device(curves, device)
-    cfg = rnn.cfg
+    wk, masks = rnn.mc_weights(n_samples, len(lengths), device, mean_field_inference)
+    cfg = rnn.infer_cfg(masks is not None)
     plan = E.Plan(cfg, lengths, device)
     xp = E.pack_ragged(cfg, plan, rows, curve_off)
-    wk, masks = rnn.mc_weights(n_samples, plan.n_curves, device, mean_field_inference)
     _, probs = E.lstm_forward(cfg, plan, xp, wk, n_samples, masks=masks, want_logits=False, want_probs=True,
                               sample_major=False)
     return probs

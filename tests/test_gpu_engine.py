@@ -261,3 +261,28 @@ def test_unsupported_shapes_fail_loudly():
         with pytest.raises(_lib.SnnError):
             E.lstm_forward_workspace_bytes(cfg, 10) if hasattr(E, "lstm_forward_workspace_bytes") else \
                 _lib.check(_lib.load().snn_lstm_forward_workspace_bytes(__import__("ctypes").byref(cfg.c), 10), "ws")
+
+
+@pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
+                                            (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
+                                            (42, 2, "mean", 2, 50, 12), (78, 14, "mean", 2, 40, 30)])
+def test_bf16x3_precision_vs_oracle(D, C, pool, L, N, T):
+    """SNN_PREC_BF16X3: every fp32 product rebuilt from six bf16 piece products on the bf16 matrix pipe.  Same
+    parity bar as the fp32 kernels (logits 5e-6 absolute, probabilities 1e-5 relative) against the C oracle, and
+    an error against the float64 oracle of the same size as the fp32 kernel's own."""
+    E = _eng()
+    H, S = 32, 2
+    cfg32 = E.Config(D, H, L, True, C, pool)
+    cfg = cfg32.with_precision("bf16x3")
+    assert cfg.supported()
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    w = _random_model(cfg, 31, 0.15)
+    x, lengths = make_curves(32, N, T, D, min_len=1)
+    lo, pr = _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(w)), S)
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])
+    _check(lo[1], pr[1], o["logits"], o["probs"])
+    lo32, _ = _run(E, cfg32, x, lengths, E.prepare_weights(cfg32, _t(w)), 1)
+    o64 = oracle.forward(ocfg, x, lengths, w, f64=True)["logits"]
+    e3, e32 = np.abs(lo[0] - o64).max(), np.abs(lo32[0] - o64).max()
+    assert e3 < 3 * e32 + 2e-7, (e3, e32)

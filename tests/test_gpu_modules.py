@@ -133,3 +133,29 @@ def test_sampled_mode_statistics(model):
         torch.manual_seed(5); b = vr.predict_mc(rnn, curves, 4).cpu().numpy()
         torch.manual_seed(6); c = vr.predict_mc(rnn, curves, 4).cpu().numpy()
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("model", ["vanilla", "bayesian"])
+def test_inference_precision_bf16x3_through_the_module_api(model):
+    """`rnn.inference_precision = "bf16x3"`: eval-mode forward, forward_mc and predict_mc run the split-bf16 kernels
+    and agree with the exact-fp32 launch of the same draws to the parity bar; training is unaffected."""
+    from supernnova_amd.validation.validate_rnn import predict_mc
+    g = load_golden("g1_vanilla_mean" if model == "vanilla" else "g3_bayesian_mean")
+    rnn = _model(model, g["sd"], 24)
+    rnn.draws = "host"
+    outs = {}
+    for prec in ("f32", "bf16x3"):
+        rnn.inference_precision = prec
+        with torch.no_grad():
+            torch.manual_seed(2000)
+            a = rnn(_packed(g)).cpu().numpy()
+            torch.manual_seed(2000)
+            b = rnn.forward_mc(_packed(g), 3).cpu().numpy()
+            curves = [g["x"][: g["lengths"][i], i] for i in range(g["x"].shape[1])]
+            torch.manual_seed(2000)
+            c = predict_mc(rnn, curves, 3).cpu().numpy()
+        outs[prec] = (a, b, c)
+    _close(torch.from_numpy(outs["bf16x3"][0]), g["logits"][0] if model == "bayesian" else g["logits"])
+    for u, v in zip(outs["f32"], outs["bf16x3"]):
+        assert rel_err(softmax_np(u) if u is outs["f32"][0] else u, softmax_np(v) if v is outs["bf16x3"][0] else v) < PROB_RTOL
+    np.testing.assert_allclose(outs["bf16x3"][1], outs["bf16x3"][2], rtol=0, atol=0)   # same launch, two entry points
