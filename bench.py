@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16 MFMA: 16 x the fp32 rate (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 
 
 def synth_curves(n, T, F_filters, device, seed, redshift=False, chunk=250_000):
@@ -200,10 +201,19 @@ def main():
         fl = flops_per_pass(cfg, int(lengths_host.astype(np.int64).sum()), N, S)
         k_ms = float(np.mean(kern_ms))
         achieved = fl / (k_ms * 1e-3) / 1e12
+        b3 = args.precision == "bf16x3"
+        peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else "lstm_fwd_pair_kernel<32,12,2>")
+        if b3:
+            # executed bf16 MFMA FLOPs: 6 piece products per fp32 product, K padded to blocks of 16
+            H, Dp16 = cfg.hidden_size, -(-cfg.input_size // 16) * 16
+            per_step = 2 * 4 * H * ((Dp16 + H) + (2 * H + H)) * 2 * 6
+            fl_exec = S * int(lengths_host.astype(np.int64).sum()) * per_step
+            achieved_f32eq, achieved = achieved, fl_exec / (k_ms * 1e-3) / 1e12
+            peak, kname = PEAK_BF16_MFMA_TFLOPS, "lstm_fwd_b3_kernel<32,2,2>"
         traffic = None   # PMC bytes per launch of this workload, from the committed rocprofv3 passes (profiles/)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
-            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len}:
+            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3:
                 traffic = tj["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -211,7 +221,8 @@ def main():
             "metric": "light curves/s classified, BayesianRNN 50 MC samples",
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (each product = 6 bf16 piece products, fp32 accumulate)" if b3 else "f32", "data": "synthetic",
             "config": {"workload": (f"BayesianRNN (BBB) LSTM 128x2 bidirectional, mean pooling, D=78 (6 filters + redshift), "
                                     f"C=14, S={S} MC samples, {args.max_len}-step sequences, {N} light curves per GPU "
                                     "(configs[4], ELAsTiCC-like)") if big else
@@ -220,11 +231,12 @@ def main():
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
                        "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
             "roofline": {"bound": "mfma",
-                         "kernel": "lstm_fwd_big_kernel<128,39,2,false>" if big else "lstm_fwd_pair_kernel<32,12,2>", "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": k_ms, "flop_per_launch": fl},
+                         "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel_ms": k_ms, "flop_per_launch": fl_exec if b3 else fl},
         }
+        if b3:
+            out["roofline"]["fp32_equivalent_tflops"] = achieved_f32eq   # algorithmic FLOPs / kernel time
         if args.cpu_curves > 0 and world == 1:
             n_cpu = min(args.cpu_curves, N)
             v, secs = cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu)
