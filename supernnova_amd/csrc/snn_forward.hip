@@ -423,7 +423,8 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
 {
     const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
     g->threads = y.H * 8;
-    g->lds = (size_t)(2 * XBM + 2 * HB) * 192 * 16 + sizeof(float) * ((size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
+    const int G = 4;   // B3_G of snn_forward_b3.hip: tiles per work item
+    g->lds = (size_t)(2 * XBM + 2 * HB) * 192 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     int dev = 0, cus = 0, per_cu = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -434,8 +435,8 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
     g->grid = cus * per_cu;
     g->cus = cus;
     g->nbuf = y.L > 2 ? 2 : 1;
-    g->y_buf_floats = (int64_t)max_T * y.dirs * HB * 192 * 4;   // [t][dir * HB blocks][3 pieces][64 lanes][8 bf16]
-    g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
+    g->y_buf_floats = (int64_t)G * max_T * y.dirs * HB * 192 * 4;   // [tile][t][dir * HB blocks][3 pieces][64 lanes][8 bf16]
+    g->ws_bytes = 1024 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
     return SNN_OK;
 }
 
@@ -461,16 +462,16 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
     p.wk = wk; p.wk_stride = wk_sample_stride;
     p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
-    p.counter = (unsigned int*)workspace;
-    p.yscratch = (float*)((char*)workspace + 256);
+    p.counter = (unsigned int*)workspace;                 // 8 per-XCD queue heads, 64 bytes apart
+    p.yscratch = (float*)((char*)workspace + 1024);
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
     B3Offsets o;
     for (int ld = 0; ld < y.L * y.dirs; ++ld) { o.k_A[ld] = y.k_A[ld]; o.k_bias[ld] = y.k_bias[ld]; }
     o.k_head_w = y.k_head_w;
     hipStream_t st = (hipStream_t)stream;
-    HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
-    const int64_t n_items = (int64_t)n_tiles * n_samples;
+    HIP_CHECK(hipMemsetAsync(workspace, 0, 1024, st));
+    const int64_t n_items = (int64_t)((n_tiles + 3) / 4) * n_samples;
     hipLaunchKernelGGL(fn, dim3((int)std::min<int64_t>(g.grid, n_items)), dim3(g.threads), g.lds, st, p, o);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;

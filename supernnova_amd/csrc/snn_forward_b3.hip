@@ -35,17 +35,24 @@ __device__ __forceinline__ float lane_select(unsigned long long mask, float a, f
     return r;
 }
 
+// Tiles of one work item: the weights of a (layer, direction) are loaded once and G tiles run through them.
+constexpr int B3_G = 4;
+struct B3Group {
+    int n;             // live tiles of the group (1..B3_G)
+    int tile0;         // first tile
+    int* info;         // LDS [B3_G][64]: lane cl -> len, 32 + cl -> orig
+};
+
 template <int H, int XB, int DIRS, bool FIRST, bool LAST>
-__device__ __forceinline__ void b3_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int64_t k_A, int64_t k_bias,
-                                         int64_t k_head_w, u32x4* xin, u32x4* hb, float* part, float* logit, float* bl,
-                                         u32x4* ybase)
+__device__ __forceinline__ void b3_phase(const FwdParams& p, ItemCtx& c, const B3Group& grp, int l, int d, int64_t k_A,
+                                         int64_t k_bias, int64_t k_head_w, u32x4* xin, u32x4* hb, float* part,
+                                         float* logit_all, float* bl, u32x4* ybase_all)
 {
     constexpr int NT = H * 8, NW = H / 8, HB = H / 16, NB = XB + HB;
     constexpr int NF4 = XB * BLK_U4, NPT = (NF4 + NT - 1) / NT;   // 16-byte words of one step's x image
     constexpr int YB = DIRS * HB;                                   // blocks of one step of the y image
     const FwdParams& y = p;
     const int ld = l * DIRS + d;
-    const int T = c.T;
 
     // ---- weight pieces -> registers: wr[b][piece] = 8 bf16 (4 VGPRs)
     bf16x8 wr[NB][3];
@@ -62,12 +69,23 @@ __device__ __forceinline__ void b3_phase(const FwdParams& p, const ItemCtx& c, i
     }
     const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
     const int j0 = 8 * c.w + 4 * c.hf;
+    const int64_t y_tile_u4 = p.y_buf_floats / 4 / B3_G;   // 16-byte words of one tile's y slab
+
+  for (int q = 0; q < grp.n; ++q) {
+    c.tile = grp.tile0 + q;
+    c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+    c.len = grp.info[q * 64 + c.cl];
+    c.orig = grp.info[q * 64 + 32 + c.cl];
+    const int T = c.T;
+    float* logit = logit_all + q * y.C * 32;
+    u32x4* ybase = ybase_all + q * y_tile_u4;
 
     // input image of step t: FIRST: the packed tile; else the y image the previous layer wrote
     // (tile_off is in fp32-image floats, T * Dp * 32 per tile; this image holds XB * BLK_U4 16-byte words per step)
     const u32x4* in0 = FIRST ? reinterpret_cast<const u32x4*>(p.xp) + p.tile_off[c.tile] / ((int64_t)p.Dp * SNN_TILE) * NF4
                              : ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats / 4;
     u32x4* yout = LAST ? nullptr : ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats / 4;
+    __syncthreads();   // the previous tile's head reduction has finished with part / logit before this tile's staging
 
     // branch-free staging: threads beyond the image duplicate its last word (same value to the same address), and
     // the last step re-stages its own image, so the loads issue at the top of the step and nothing is predicated
@@ -208,6 +226,7 @@ __device__ __forceinline__ void b3_phase(const FwdParams& p, const ItemCtx& c, i
         }
     }
     __syncthreads();  // also publishes this phase's y stores to the workgroup
+  }
 }
 
 template <int H, int XB0, int DIRS>
@@ -221,9 +240,10 @@ __global__ void __launch_bounds__(H * 8, SNN_B3_WAVES) lstm_fwd_b3_kernel(const 
     u32x4* xin = reinterpret_cast<u32x4*>(smem);            // [2][XBM blocks]
     u32x4* hb = xin + 2 * XBM * BLK_U4;                     // [2][HB blocks]
     float* part = reinterpret_cast<float*>(hb + 2 * HB * BLK_U4);   // [NW][C][32]
-    float* logit = part + NW * y.C * 32;                    // [C][32]
-    float* bl = logit + y.C * 32;                           // [NW][2][16]
-    int* item_slot = reinterpret_cast<int*>(bl + NW * 32);
+    float* logit = part + NW * y.C * 32;                    // [B3_G][C][32]
+    float* bl = logit + B3_G * y.C * 32;                    // [NW][2][16]
+    int* info = reinterpret_cast<int*>(bl + NW * 32);       // [B3_G][64]
+    int* item_slot = info + B3_G * 64;
 
     ItemCtx c;
     c.tid = threadIdx.x;
@@ -234,54 +254,70 @@ __global__ void __launch_bounds__(H * 8, SNN_B3_WAVES) lstm_fwd_b3_kernel(const 
     c.tape = nullptr;
     c.ybase = nullptr;
     u32x4* ybase = reinterpret_cast<u32x4*>(p.yscratch) + (int64_t)blockIdx.x * p.nbuf * p.y_buf_floats / 4;
-    const int64_t n_items = (int64_t)p.n_tiles * p.n_samples;
+    // Work queues, one per XCD (workgroups are dispatched round-robin over the 8 XCDs, each with its own L2):
+    // queue x holds the tile groups x, x + 8, ... with all MC samples of a group adjacent, so the x image of a
+    // group is fetched into ONE L2 and shared by its S items.  An XCD that runs dry steals from the next queue.
+    const int n_groups = (p.n_tiles + B3_G - 1) / B3_G;
+    const int xcd = blockIdx.x & 7;
+    B3Group grp;
+    grp.info = info;
 
-    for (;;) {
-        if (c.tid == 0) *item_slot = (int)atomicAdd(p.counter, 1u);
-        __syncthreads();
-        const int item = __builtin_amdgcn_readfirstlane(*item_slot);
-        if (item >= n_items) break;
-        c.tile = item / p.n_samples;
-        c.s = item - c.tile * p.n_samples;
-        c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
-        const int pos = c.tile * SNN_TILE + c.cl;
-        c.len = p.len_sorted[pos];
-        c.orig = p.order[pos];
-        c.wks = p.wk + (int64_t)c.s * p.wk_stride;
-        for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
-        __syncthreads();
+    for (int k = 0; k < 8; ++k) {
+        const int qx = (xcd + k) & 7;
+        const int64_t n_items = (int64_t)((n_groups - qx + 7) / 8) * p.n_samples;
+        for (;;) {
+            if (c.tid == 0) *item_slot = (int)atomicAdd(p.counter + qx * 16, 1u);
+            __syncthreads();
+            const int item = __builtin_amdgcn_readfirstlane(*item_slot);
+            if (item >= n_items) break;
+            const int g = qx + 8 * (item / p.n_samples);
+            c.s = item % p.n_samples;
+            grp.tile0 = g * B3_G;
+            grp.n = min(B3_G, p.n_tiles - grp.tile0);
+            c.wks = p.wk + (int64_t)c.s * p.wk_stride;
+            for (int idx = c.tid; idx < grp.n * 64; idx += NT) {
+                const int q = idx >> 6, r = idx & 63;
+                const int pos = (grp.tile0 + q) * SNN_TILE + (r & 31);
+                info[idx] = r < 32 ? p.len_sorted[pos] : p.order[pos];
+            }
+            for (int idx = c.tid; idx < B3_G * y.C * 32; idx += NT) logit[idx] = 0.0f;
+            __syncthreads();
 
-        for (int l = 0; l < y.L; ++l) {
-            const bool last = l == y.L - 1;
-            for (int d = 0; d < DIRS; ++d) {
-                const int ld = l * DIRS + d;
-                if (l == 0) {
-                    if (last) b3_phase<H, XB0, DIRS, true, true>(p, c, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                    else b3_phase<H, XB0, DIRS, true, false>(p, c, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                } else {
-                    if (last) b3_phase<H, XB1, DIRS, false, true>(p, c, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                    else b3_phase<H, XB1, DIRS, false, false>(p, c, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+            for (int l = 0; l < y.L; ++l) {
+                const bool last = l == y.L - 1;
+                for (int d = 0; d < DIRS; ++d) {
+                    const int ld = l * DIRS + d;
+                    if (l == 0) {
+                        if (last) b3_phase<H, XB0, DIRS, true, true>(p, c, grp, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else b3_phase<H, XB0, DIRS, true, false>(p, c, grp, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                    } else {
+                        if (last) b3_phase<H, XB1, DIRS, false, true>(p, c, grp, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else b3_phase<H, XB1, DIRS, false, false>(p, c, grp, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                    }
                 }
             }
-        }
 
-        if (c.tid < 32) {
-            const int orig = c.orig;
-            if (orig >= 0) {
-                const float* bo = c.wks + o.k_head_w + y.C * y.F;
-                float mx = -INFINITY;
-                for (int q = 0; q < y.C; ++q) mx = fmaxf(mx, logit[q * 32 + c.tid] + bo[q]);
-                float z = 0.0f;
-                for (int q = 0; q < y.C; ++q) z += expf(logit[q * 32 + c.tid] + bo[q] - mx);
-                const int64_t off = (int64_t)c.s * p.os_s + (int64_t)orig * p.os_n;
-                for (int q = 0; q < y.C; ++q) {
-                    const float lg = logit[q * 32 + c.tid] + bo[q];
-                    if (p.out_logits) p.out_logits[off + q] = lg;
-                    if (p.out_probs) p.out_probs[off + q] = __fdiv_rn(expf(lg - mx), z);
+            // ---- head bias + softmax, one thread per curve of the group
+            for (int idx = c.tid; idx < grp.n * 32; idx += NT) {
+                const int q = idx >> 5, cc = idx & 31;
+                const int orig = info[q * 64 + 32 + cc];
+                if (orig >= 0) {
+                    const float* lg_ = logit + q * y.C * 32;
+                    const float* bo = c.wks + o.k_head_w + y.C * y.F;
+                    float mx = -INFINITY;
+                    for (int k2 = 0; k2 < y.C; ++k2) mx = fmaxf(mx, lg_[k2 * 32 + cc] + bo[k2]);
+                    float z = 0.0f;
+                    for (int k2 = 0; k2 < y.C; ++k2) z += expf(lg_[k2 * 32 + cc] + bo[k2] - mx);
+                    const int64_t off = (int64_t)c.s * p.os_s + (int64_t)orig * p.os_n;
+                    for (int k2 = 0; k2 < y.C; ++k2) {
+                        const float lg = lg_[k2 * 32 + cc] + bo[k2];
+                        if (p.out_logits) p.out_logits[off + k2] = lg;
+                        if (p.out_probs) p.out_probs[off + k2] = __fdiv_rn(expf(lg - mx), z);
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 

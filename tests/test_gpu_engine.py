@@ -286,3 +286,27 @@ def test_bf16x3_precision_vs_oracle(D, C, pool, L, N, T):
     o64 = oracle.forward(ocfg, x, lengths, w, f64=True)["logits"]
     e3, e32 = np.abs(lo[0] - o64).max(), np.abs(lo32[0] - o64).max()
     assert e3 < 3 * e32 + 2e-7, (e3, e32)
+
+
+def test_bf16x3_large_batch_properties():
+    """bf16x3 at a size with many tile groups spread over the per-XCD queues: shuffling the curves permutes the
+    outputs bit-for-bit, and the probabilities agree with the exact-fp32 launch to the parity bar."""
+    E = _eng()
+    D, H, C, S, N, T = 24, 32, 2, 3, 9001, 40
+    cfg32 = E.Config(D, H, 2, True, C, "mean")
+    cfg = cfg32.with_precision("bf16x3")
+    g = np.random.default_rng(18)
+    mu = g.uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    rho = g.uniform(-4, -2, cfg.P - C).astype(np.float32)
+    eps = g.standard_normal((S, cfg.P - C)).astype(np.float32)
+    x, lengths = make_curves(19, N, T, D, min_len=3)
+    wk, kl = E.bbb_sample(cfg, _t(mu), _t(rho), S, E.Prior(), eps=_t(eps))
+    wk32, kl32 = E.bbb_sample(cfg32, _t(mu), _t(rho), S, E.Prior(), eps=_t(eps))
+    assert torch.equal(kl, kl32)                       # the KL does not depend on the weight image format
+    lo, pr = _run(E, cfg, x, lengths, wk, S)
+    perm = g.permutation(N)
+    lo2, pr2 = _run(E, cfg, np.ascontiguousarray(x[:, perm]), lengths[perm], wk, S)
+    assert np.array_equal(pr2, pr[:, perm]) and np.array_equal(lo2, lo[:, perm])
+    lo32, pr32 = _run(E, cfg32, x, lengths, wk32, S)
+    np.testing.assert_allclose(lo, lo32, atol=LOGIT_ATOL, rtol=0)
+    assert rel_err(pr, pr32) < PROB_RTOL
