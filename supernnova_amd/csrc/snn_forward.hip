@@ -238,6 +238,7 @@ fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forw
 fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pair.hip
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
+fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs);     // snn_forward_b3p.hip (same, two tiles per workgroup)
 static const FwdEntry* find_fwd(const SnnLayout& y)
 {
     static thread_local FwdEntry ent;
@@ -448,6 +449,11 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
 {
     fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
     if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (n_tiles > 1) {   // two tiles per workgroup, software-pipelined (snn_forward_b3p.hip); bit-identical results
+        static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
+        fwd_b3_kernel_t fp = no_pair ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs);
+        if (fp) fn = fp;
+    }
     FwdGeom g;
     int rc = b3_geom(y, fn, max_T, &g);
     if (rc) return rc;
@@ -486,8 +492,12 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
         fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
         if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
         if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
-        FwdGeom g;
+        FwdGeom g, gp;
         rc = b3_geom(y, fn, max_T, &g);
+        if (fwd_b3_kernel_t fp = rc ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs)) {
+            rc = b3_geom(y, fp, max_T, &gp);
+            if (!rc) g.ws_bytes = std::max(g.ws_bytes, gp.ws_bytes);
+        }
         return rc ? rc : g.ws_bytes;
     }
     const FwdEntry* e = find_fwd(y);

@@ -135,6 +135,9 @@ __device__ __forceinline__ void b3_phase(const FwdParams& p, ItemCtx& c, const B
         const u32x4* hc = hb + cur * (HB * BLK_U4) + c.lane;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+#ifdef SNN_ABL_NOMFMA   // timing ablation only: one block of products instead of NB
+            if (b > 0) break;
+#endif
             const u32x4* src = b < XB ? xc + b * BLK_U4 : hc + (b - XB) * BLK_U4;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, src[0]);
             const bf16x8 bm = __builtin_bit_cast(bf16x8, src[64]);

@@ -310,3 +310,26 @@ def test_bf16x3_large_batch_properties():
     lo32, pr32 = _run(E, cfg32, x, lengths, wk32, S)
     np.testing.assert_allclose(lo, lo32, atol=LOGIT_ATOL, rtol=0)
     assert rel_err(pr, pr32) < PROB_RTOL
+
+
+@pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
+                                            (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
+                                            (24, 2, "mean", 2, 33, 1), (78, 14, "mean", 2, 161, 12)])
+def test_bf16x3_paired_kernel_matches_one_tile_kernel(D, C, pool, L, N, T):
+    """bf16x3 over more than one tile runs the two-tiles-per-workgroup pipeline (snn_forward_b3p.hip); a batch of
+    <= 32 curves runs the one-tile kernel (snn_forward_b3.hip).  Same products in the same order: the same curves
+    must give bit-identical results through both (odd tile counts, groups of 1..4 tiles, partners of different
+    length, 1..3 layers, both poolings)."""
+    E = _eng()
+    H, S = 32, 2
+    cfg = E.Config(D, H, L, True, C, pool).with_precision("bf16x3")
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    w = _random_model(cfg, 33, 0.15)
+    x, lengths = make_curves(34, N, T, D, min_len=1)
+    wk = E.prepare_weights(cfg, _t(w))
+    lo, pr = _run(E, cfg, x, lengths, wk, S)
+    for a in range(0, N, 32):
+        lo1, pr1 = _run(E, cfg, np.ascontiguousarray(x[:, a:a + 32]), lengths[a:a + 32], wk, S)
+        assert np.array_equal(lo1, lo[:, a:a + 32]) and np.array_equal(pr1, pr[:, a:a + 32])
+    o = oracle.forward(ocfg, x, lengths, w)
+    _check(lo[0], pr[0], o["logits"], o["probs"])
