@@ -122,9 +122,9 @@ def main():
                     help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
                          "(H=128, 6 filters + redshift, 14 classes, 300-step sequences) -- a secondary measurement")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
-                    help="f32: every gate product in fp32 (default); bf16x3: each fp32 product rebuilt from six bf16 "
-                         "piece products on the bf16 matrix pipe (fp32-equivalent accuracy, include/snn_hip.h)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
+                    help="f32: every gate product in fp32 (default); bf16x3 / f16x2: each fp32 product rebuilt from six "
+                         "bf16 / three fp16 piece products on the 16-bit matrix pipe (include/snn_hip.h)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,15 +201,16 @@ def main():
         fl = flops_per_pass(cfg, int(lengths_host.astype(np.int64).sum()), N, S)
         k_ms = float(np.mean(kern_ms))
         achieved = fl / (k_ms * 1e-3) / 1e12
-        b3 = args.precision == "bf16x3"
+        b3 = args.precision != "f32"
+        npr = 6 if args.precision == "bf16x3" else 3     # piece products per fp32 product
         peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else "lstm_fwd_pair_kernel<32,12,2>")
         if b3:
-            # executed bf16 MFMA FLOPs: 6 piece products per fp32 product, K padded to blocks of 16
+            # executed 16-bit MFMA FLOPs: 6 (bf16x3) / 3 (f16x2) piece products per fp32 product, K padded to blocks of 16
             H, Dp16 = cfg.hidden_size, -(-cfg.input_size // 16) * 16
-            per_step = 2 * 4 * H * ((Dp16 + H) + (2 * H + H)) * 2 * 6
+            per_step = 2 * 4 * H * ((Dp16 + H) + (2 * H + H)) * 2 * npr
             fl_exec = S * int(lengths_host.astype(np.int64).sum()) * per_step
             achieved_f32eq, achieved = achieved, fl_exec / (k_ms * 1e-3) / 1e12
-            peak, kname = PEAK_BF16_MFMA_TFLOPS, "lstm_fwd_b3_kernel<32,2,2>"
+            peak, kname = PEAK_BF16_MFMA_TFLOPS, ("lstm_fwd_b3p_kernel<32,2,2>" if npr == 6 else "lstm_fwd_h2_kernel<32,2,2>")
         traffic = None   # PMC bytes per launch of this workload, from the committed rocprofv3 passes (profiles/)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
@@ -222,7 +223,8 @@ def main():
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (each product = 6 bf16 piece products, fp32 accumulate)" if b3 else "f32", "data": "synthetic",
+            "dtype": (f"f32 (each product = {npr} {'bf16' if npr == 6 else 'fp16'} piece products, fp32 accumulate)"
+                      if b3 else "f32"), "data": "synthetic",
             "config": {"workload": (f"BayesianRNN (BBB) LSTM 128x2 bidirectional, mean pooling, D=78 (6 filters + redshift), "
                                     f"C=14, S={S} MC samples, {args.max_len}-step sequences, {N} light curves per GPU "
                                     "(configs[4], ELAsTiCC-like)") if big else

@@ -69,9 +69,17 @@ typedef struct snn_cfg {
  *                  image have a different size and layout in this mode: snn_x_step_floats / snn_kparam_count
  *                  report it, and snn_pack_x, snn_prepare_weights, snn_bbb_sample and snn_lstm_forward must all
  *                  be called with the same precision.
+ * SNN_PREC_F16X2   inference only: x, h and W are cut into 2 fp16 pieces, v = hi + lo * 2^-11 (hi = fp16(v),
+ *                  lo = fp16((v - hi) * 2^11): one fp32 ulp at worst, exact for 3 values in 4), and every fp32
+ *                  product is rebuilt from 3 fp16 products (hi*hi into one fp32 accumulator, hi*lo + lo*hi into a
+ *                  second one, combined as main + 2^-11 * cross; the dropped lo*lo term is below 2^-22 relative,
+ *                  2^-25 RMS) on v_mfma_f32_32x32x16_f16.  Half the matrix work of BF16X3 at an error of about
+ *                  twice fp32 rounding; same parity bar.  Requires |x| < 65504 (normalised features): a larger
+ *                  input has no fp16 and yields NaN probabilities for its light curve.  Layout rules as BF16X3.
  */
 #define SNN_PREC_F32 0
 #define SNN_PREC_BF16X3 1
+#define SNN_PREC_F16X2 2
 
 /* Prior of training/bayesian_rnn.py:753-763 (LSTM prior, then the head's). */
 typedef struct snn_prior {

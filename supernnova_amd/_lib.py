@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")  # env override: A/B builds
 
 SNN_POOL_MEAN, SNN_POOL_STANDARD = 0, 1
-SNN_PREC_F32, SNN_PREC_BF16X3 = 0, 1
+SNN_PREC_F32, SNN_PREC_BF16X3, SNN_PREC_F16X2 = 0, 1, 2
 SNN_MASK_NONE, SNN_MASK_ARRAYS, SNN_MASK_PHILOX = 0, 1, 2
 BBB_EPS, BBB_MFE, BBB_PHILOX = 0, 1, 2
 TILE = 32

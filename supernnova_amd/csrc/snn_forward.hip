@@ -21,6 +21,8 @@
 // ============================================================================
 // precision 1: xp3[tile][t][XB][3 pieces][64 lanes][8 bf16], lane (curve = lane & 31, khalf = lane >> 5) holds features
 // 16 b + 8 khalf + e -- the B operand of v_mfma_f32_32x32x16_bf16, three times (hi, mid, lo)
+// precision 2 (NPC == 2): the same image with two fp16 pieces (split2)
+template <int NPC>
 __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, const float* __restrict__ x,
                                                      int64_t stride_t, int64_t stride_n,
                                                      const int64_t* __restrict__ curve_off,
@@ -32,7 +34,7 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
 {
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
-    const int64_t step_bf16 = (int64_t)XB * 3 * 64 * 8;
+    const int64_t step_bf16 = (int64_t)XB * NPC * 64 * 8;
     __bf16* dst = xp + tile_off[tile] / ((int64_t)Dp * SNN_TILE) * step_bf16;
     for (int idx = threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x) {
         const int t = idx >> 5, c = idx & 31;
@@ -44,12 +46,19 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
         __bf16* o = dst + (int64_t)t * step_bf16;
         for (int k = 0; k < 16 * XB; ++k) {
             const float v = (live && k < D) ? src[k] : 0.0f;
-            __bf16 h, m, l;
-            split3(v, h, m, l);
-            const int64_t a = ((((int64_t)(k >> 4) * 3) * 64) + ((k >> 3) & 1) * 32 + c) * 8 + (k & 7);
-            o[a] = h;
-            o[a + 64 * 8] = m;
-            o[a + 2 * 64 * 8] = l;
+            const int64_t a = ((((int64_t)(k >> 4) * NPC) * 64) + ((k >> 3) & 1) * 32 + c) * 8 + (k & 7);
+            if (NPC == 3) {
+                __bf16 h, m, l;
+                split3(v, h, m, l);
+                o[a] = h;
+                o[a + 64 * 8] = m;
+                o[a + 2 * 64 * 8] = l;
+            } else {
+                _Float16 h, l;
+                split2(v, h, l);
+                reinterpret_cast<_Float16*>(o)[a] = h;
+                reinterpret_cast<_Float16*>(o)[a + 64 * 8] = l;
+            }
         }
     }
 }
@@ -142,6 +151,13 @@ __global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const floa
             d3[0] = wh;
             d3[64 * 8] = wm;
             d3[2 * 64 * 8] = wl;
+        } else if (y.prec == 2 && g.kind <= 1) {
+            // the row's gate factor goes into the weight (one fp32 rounding), then the two fp16 pieces
+            _Float16 wh, wl;
+            split2(__fmul_rn(w, h2_gate_scale((int)(i / g.cols) / y.H)), wh, wl);
+            _Float16* d2 = reinterpret_cast<_Float16*>(dst) + kernel_index3(y, g, i);
+            d2[0] = wh;
+            d2[64 * 8] = wl;
         } else {
             dst[kernel_index(y, g, i)] = w;
         }
@@ -219,7 +235,7 @@ extern "C" int64_t snn_x_step_floats(const snn_cfg* cfg)
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    return y.prec == 1 ? (int64_t)y.XB[0] * 3 * 64 * 4 : (int64_t)y.Dp * SNN_TILE;
+    return y.prec != 0 ? (int64_t)y.XB[0] * y.NPC * 64 * 4 : (int64_t)y.Dp * SNN_TILE;
 }
 extern "C" int32_t snn_feat(const snn_cfg* cfg)
 {
@@ -239,6 +255,7 @@ fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pai
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
 fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs);     // snn_forward_b3p.hip (same, two tiles per workgroup)
+fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs);      // snn_forward_h2.hip (SNN_PREC_F16X2)
 static const FwdEntry* find_fwd(const SnnLayout& y)
 {
     static thread_local FwdEntry ent;
@@ -261,6 +278,7 @@ extern "C" int snn_supported(const snn_cfg* cfg)
     SnnLayout y;
     if (snn_make_layout(cfg, &y)) return 0;
     if (y.prec == 1) return snn_b3_kernel(y.H, y.XB[0], y.dirs) != nullptr;
+    if (y.prec == 2) return snn_h2_kernel(y.H, y.XB[0], y.dirs) != nullptr;
     return find_fwd(y) != nullptr;
 }
 
@@ -321,9 +339,10 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
         return SNN_ERR_ARG;
     }
     (void)xp_floats;
-    if (y.prec == 1) {
-        hipLaunchKernelGGL(pack_x3_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t,
-                           stride_n, curve_off, order, len_sorted, tile_T, tile_off, reinterpret_cast<__bf16*>(xp));
+    if (y.prec != 0) {
+        hipLaunchKernelGGL(y.prec == 1 ? pack_x3_kernel<3> : pack_x3_kernel<2>, dim3(n_tiles), dim3(256), 0,
+                           (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t, stride_n, curve_off, order, len_sorted,
+                           tile_T, tile_off, reinterpret_cast<__bf16*>(xp));
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
@@ -337,7 +356,7 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
                          float* kl_terms, hipStream_t st)
 {
-    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec == 1)  // padding words exist: define them
+    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0)  // padding words exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
     hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
                        offset, prior, wk, kl ? kl_terms : nullptr);
@@ -425,7 +444,7 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
     const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
     g->threads = y.H * 8;
     const int G = 4;   // B3_G of snn_forward_b3.hip: tiles per work item
-    g->lds = (size_t)(2 * XBM + 2 * HB) * 192 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
+    g->lds = (size_t)(2 * XBM + 2 * HB) * y.NPC * 64 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     int dev = 0, cus = 0, per_cu = 0;
     HIP_CHECK(hipGetDevice(&dev));
@@ -436,7 +455,7 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
     g->grid = cus * per_cu;
     g->cus = cus;
     g->nbuf = y.L > 2 ? 2 : 1;
-    g->y_buf_floats = (int64_t)G * max_T * y.dirs * HB * 192 * 4;   // [tile][t][dir * HB blocks][3 pieces][64 lanes][8 bf16]
+    g->y_buf_floats = (int64_t)G * max_T * y.dirs * HB * y.NPC * 64 * 4;   // [tile][t][dir * HB blocks][pieces][64 lanes][8 x 16 bit]
     g->ws_bytes = 1024 + (int64_t)sizeof(float) * g->grid * g->nbuf * g->y_buf_floats;
     return SNN_OK;
 }
@@ -447,9 +466,9 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
                              float* out_logits, float* out_probs, int64_t out_stride_sample, int64_t out_stride_curve,
                              void* workspace, int64_t workspace_bytes, void* stream)
 {
-    fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
-    if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
-    if (n_tiles > 1) {   // two tiles per workgroup, software-pipelined (snn_forward_b3p.hip); bit-identical results
+    fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
+    if (!fn) { snn_set_error("no split-precision forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (y.prec == 1 && n_tiles > 1) {   // two tiles per workgroup, software-pipelined (snn_forward_b3p.hip); bit-identical results
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
         fwd_b3_kernel_t fp = no_pair ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs);
         if (fp) fn = fp;
@@ -488,13 +507,13 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    if (y.prec == 1) {
-        fwd_b3_kernel_t fn = snn_b3_kernel(y.H, y.XB[0], y.dirs);
-        if (!fn) { snn_set_error("no bf16x3 forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (y.prec != 0) {
+        fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
+        if (!fn) { snn_set_error("no split-precision forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
         if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
         FwdGeom g, gp;
         rc = b3_geom(y, fn, max_T, &g);
-        if (fwd_b3_kernel_t fp = rc ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs)) {
+        if (fwd_b3_kernel_t fp = (rc || y.prec != 1) ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs)) {
             rc = b3_geom(y, fp, max_T, &gp);
             if (!rc) g.ws_bytes = std::max(g.ws_bytes, gp.ws_bytes);
         }
@@ -557,8 +576,8 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
         snn_set_error("snn_lstm_forward: null pointer");
         return SNN_ERR_ARG;
     }
-    if (y.prec == 1 && (train || (masks && masks->mode != SNN_MASK_NONE))) {
-        snn_set_error("SNN_PREC_BF16X3 is implemented for un-masked inference only");
+    if (y.prec != 0 && (train || (masks && masks->mode != SNN_MASK_NONE))) {
+        snn_set_error("SNN_PREC_BF16X3 / SNN_PREC_F16X2 are implemented for un-masked inference only");
         return SNN_ERR_UNSUPPORTED;
     }
     if (n_curves < 1 || n_tiles != (n_curves + SNN_TILE - 1) / SNN_TILE || max_T < 1 || n_samples < 1 ||
@@ -568,7 +587,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                       n_tiles, max_T, n_samples);
         return SNN_ERR_ARG;
     }
-    if (y.prec == 1)
+    if (y.prec != 0)
         return launch_forward_b3(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, wk_sample_stride,
                                  n_samples, out_logits, out_probs, out_stride_sample, out_stride_curve, workspace,
                                  workspace_bytes, stream);

@@ -1,19 +1,19 @@
-// snn_forward_b3p.hip -- bf16 x 3 LSTM forward (see snn_forward_b3.hip for the arithmetic), two 32-curve tiles per
-// workgroup with the time loop software-pipelined across the pair:
+// snn_forward_h2.hip -- persistent LSTM forward with the gate products on the fp16 matrix pipe (SNN_PREC_F16X2):
+// every operand (x_t, h_{t-1}, W) is carried as two fp16 pieces, v = hi + lo * 2^-11 (split2, snn_kernels.h), and each
+// fp32 product is rebuilt from three piece products
+//     main  += hi * hi            cross += hi * lo + lo * hi            gate = main + 2^-11 * cross
+// (fp16 x fp16 is exact in fp32; the dropped lo * lo term is < 2^-22 relative, 2^-25 RMS), accumulated in fp32 by
+// v_mfma_f32_32x32x16_f16 in two independent accumulator chains.  Why, after bf16 x 3 (snn_forward_b3p.hip): that
+// kernel is limited by the power its 24 / 36 MFMAs per step draw (the clock falls from 2.4 to 1.6 GHz,
+// profiles/r1/README.md) and by ~145 VALU instructions per step; here the matrix work is halved, the exp2 scale of
+// every gate is folded into the weight rows and biases (h2_gate_scale), and the cell update runs on packed fp32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) over pairs of hidden units.
 //
-//     phase I : MFMA chain of tile 1, step t      ||  cell update of tile 0, step t   -> h0_t pieces to LDS
-//     barrier
-//     phase II: MFMA chain of tile 0, step t + 1  ||  cell update of tile 1, step t   -> h1_t pieces to LDS
-//     barrier
-//
-// Why: timing ablations of the one-tile kernel (profiles/r1/README.md) show its time is the SUM of the MFMA chain
-// (24 / 36 dependent v_mfma_f32_32x32x16_bf16 per step), the cell's VALU work and the y traffic: other waves of the SIMD
-// do not fill the matrix pipe while a wave computes its cell.  The bf16 MFMA does run concurrently with VALU issued
-// by the SAME wave (microbench/mfma_valu_overlap.hip), so here every wave always has a chain in flight whose result
-// it does not need yet, and the other tile's cell update, bf16 split and stores are cut into pieces placed behind
-// its MFMAs.  Same products in the same order as the one-tile kernel: results are bit-identical.
-// The x / y image of step t + 2 is requested right after the image of step t + 1 went to LDS (two phases of latency
-// hiding).  Inference only, no masks, H = 32 (SNN_PREC_BF16X3; include/snn_hip.h).
+// Same decomposition and pipeline as snn_forward_b3p.hip: item = (group of 4 tiles, MC sample), two tiles at a time,
+//     phase I : MFMA chains of tile 1, step t      ||  cell update of tile 0, step t   -> h0_t pieces to LDS
+//     phase II: MFMA chains of tile 0, step t + 1  ||  cell update of tile 1, step t   -> h1_t pieces to LDS
+// One kernel for every batch size (a lone tile runs with a dead partner), so results do not depend on how the
+// curves are tiled.  Inference only, no masks, H = 32.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -21,15 +21,16 @@
 #include "snn_kernels.h"
 #include "snn_host.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-#ifndef SNN_B3P_WAVES
-#define SNN_B3P_WAVES 2
+#ifndef SNN_H2_WAVES
+#define SNN_H2_WAVES 2
 #endif
 
-constexpr int BLK_U4 = 3 * 64;   // uint4 (16-byte) words of one K=16 block: 3 pieces x 64 lanes
-constexpr int B3_G = 4;          // tiles of one work item (two pairs), as in snn_forward_b3.hip
+constexpr int BLK_U4 = 2 * 64;   // uint4 (16-byte) words of one K=16 block: 2 pieces x 64 lanes
+constexpr int B3_G = 4;          // tiles of one work item (two pairs)
 
 __device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
 {
@@ -37,43 +38,46 @@ __device__ __forceinline__ float lane_select(unsigned long long mask, float a, f
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
     return r;
 }
-// two floats -> two bf16 (round to nearest even) in one register, low half = a
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b)
+// two floats -> two fp16 (round to nearest even) in one register, low half = a
+__device__ __forceinline__ unsigned int cvt_pk_f16(float a, float b)
 {
     unsigned int r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ f2 exp2_2(f2 v) { return f2{__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)}; }
+__device__ __forceinline__ f2 rcp_2(f2 v) { return f2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+__device__ __forceinline__ f2 fma_2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-struct B3PCtx {
+struct H2Ctx {
     int s, w, lane, cl, hf, tid;
     const float* wks;
 };
 
 template <int H, int XB, int DIRS, bool FIRST, bool LAST>
-__device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, int n_live, int tile0, const int* info,
-                                          int l, int d, int64_t k_A, int64_t k_bias, int64_t k_head_w, u32x4* xin,
-                                          u32x4* hb, float* part, float* logit_all, float* bl, u32x4* ybase_all)
+__device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int n_live, int tile0, const int* info,
+                                         int l, int d, int64_t k_A, int64_t k_bias, int64_t k_head_w, u32x4* xin,
+                                         u32x4* hb, float* part, float* logit_all, float* bl, u32x4* ybase_all)
 {
-    constexpr int NT = H * 8, NW = H / 8, HB = H / 16, NB = XB + HB, NM = NB * 6;
+    constexpr int NT = H * 8, NW = H / 8, HB = H / 16, NB = XB + HB, NM = NB * 3;
     constexpr int NF4 = XB * BLK_U4, NPT = (NF4 + NT - 1) / NT;   // 16-byte words of one step's x image
     constexpr int YB = DIRS * HB;                                   // blocks of one step of the y image
     constexpr int XS = XB * BLK_U4, HS = HB * BLK_U4;               // LDS words of one tile's x / h image
     const FwdParams& y = p;
     const int ld = l * DIRS + d;
 
-    // ---- weight pieces -> registers, shared by both tiles: wr[b][piece] = 8 bf16 (4 VGPRs)
-    bf16x8 wr[NB][3];
+    // ---- weight pieces -> registers, shared by both tiles: wr[b][piece] = 8 fp16 (4 VGPRs)
+    f16x8 wr[NB][2];
     {
         const u32x4* A = reinterpret_cast<const u32x4*>(c.wks + k_A) + (int64_t)c.w * NB * BLK_U4 + c.lane;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) wr[b][q] = __builtin_bit_cast(bf16x8, A[(b * 3 + q) * 64]);
+            for (int q = 0; q < 2; ++q) wr[b][q] = __builtin_bit_cast(f16x8, A[(b * 2 + q) * 64]);
     }
-    if (c.cl < 16) {
+    if (c.cl < 16) {   // b_ih + b_hh in C/D register order (entry i: gate i >> 2), times the gate's exp2 factor
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
-        bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
+        bl[(c.w * 2 + c.hf) * 16 + c.cl] = __fmul_rn(B[c.cl] + B[NW * 32 + c.cl], h2_gate_scale(c.cl >> 2));
     }
     const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
     const int j0 = 8 * c.w + 4 * c.hf;
@@ -125,35 +129,31 @@ __device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, i
         }
     };
 
-    float cst[2][4], hst[2][4], hsum[2][4];
+    // state of the lane's 4 hidden units as two pairs (packed fp32 math works on register pairs)
+    f2 cst[2][2], hst[2][2], hsum[2][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cst[q][u] = hst[q][u] = hsum[q][u] = 0.0f;
+        for (int k = 0; k < 2; ++k) cst[q][k] = hst[q][k] = hsum[q][k] = f2{0.0f, 0.0f};
 
-    // The cell update of one tile-step in NPIECE pieces: 6 per hidden unit (the three gates, the cell, tanh(c), h),
-    // the bf16 split of units 0-1 / 2-3, and the stores.  They are spread evenly over the NM MFMAs of the other
-    // tile's chain (~32 cycles of matrix time each: room for about 6 VALU instructions).
-    constexpr int NPIECE = 27;
-    struct ActRegs { float ig[4], fg[4], gg[4], og[4], tc[4]; unsigned int ph[2], pm[2], pl[2]; };
-    auto split_pair = [&](int qa, ActRegs& r, int k) {   // units 2k, 2k+1 -> hi / mid / lo pieces
-        const float a = hst[qa][2 * k], b = hst[qa][2 * k + 1];
-        const unsigned int hi = cvt_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-        const unsigned int mid = cvt_pk_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
-        r.ph[k] = hi; r.pm[k] = mid; r.pl[k] = cvt_pk_bf16(sa, sb);
-    };
-    auto act_piece = [&](int qa, int ta, const f32x16& acc, ActRegs& r, unsigned long long vmask, unsigned int vbits,
-                         int piece) {
+    // The cell update of one tile-step in NPIECE pieces: 8 per pair of hidden units, then the stores.  They are spread
+    // evenly over the NM MFMAs of the other tile's chains.  All gate pre-activations arrive scaled for exp2.
+    constexpr int NPIECE = 17;
+    struct ActRegs { f2 di[2], dg[2], df[2], dc[2], dq[2], ig[2], gg[2]; unsigned int ph[2], pl[2]; };
+    auto act_piece = [&](int qa, int ta, const f32x16& aM, const f32x16& aX, ActRegs& r, unsigned long long vmask,
+                         unsigned int vbits, int piece) {
         // `pin`: an empty volatile asm on the piece's input keeps the piece behind the sched_barrier before it
-        auto pin = [](float v) { asm volatile("" : "+v"(v)); return v; };
-        if (piece == 12 || piece == 25) { split_pair(qa, r, piece == 12 ? 0 : 1); return; }
-        if (piece == 26) {
+        auto pin = [](f2 v) { asm volatile("" : "+v"(v)); return v; };
+        // gate g of pair k: main + 2^-11 * cross
+        auto gate = [&](int g, int k) {
+            return fma_2(f2{aX[4 * g + 2 * k], aX[4 * g + 2 * k + 1]}, f2{SNN_H2_LO_INV, SNN_H2_LO_INV},
+                         f2{aM[4 * g + 2 * k], aM[4 * g + 2 * k + 1]});
+        };
+        const f2 one = f2{1.0f, 1.0f}, mtwo = f2{-2.0f, -2.0f};
+        if (piece == 16) {
             u32x4* hn = hb + qa * HS;
-            reinterpret_cast<uint2*>(hn + (hblk * 3 + 0) * 64 + hlane)[c.hf] = uint2{r.ph[0], r.ph[1]};
-            reinterpret_cast<uint2*>(hn + (hblk * 3 + 1) * 64 + hlane)[c.hf] = uint2{r.pm[0], r.pm[1]};
-            reinterpret_cast<uint2*>(hn + (hblk * 3 + 2) * 64 + hlane)[c.hf] = uint2{r.pl[0], r.pl[1]};
+            reinterpret_cast<uint2*>(hn + (hblk * 2 + 0) * 64 + hlane)[c.hf] = uint2{r.ph[0], r.ph[1]};
+            reinterpret_cast<uint2*>(hn + (hblk * 2 + 1) * 64 + hlane)[c.hf] = uint2{r.pl[0], r.pl[1]};
             if (!LAST) {
                 u32x4* yo = yout[qa] + ((int64_t)ta * YB + d * HB + hblk) * BLK_U4 + hlane;
 #ifdef SNN_ABL_NOYST   // timing ablation only
@@ -161,78 +161,90 @@ __device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, i
 #endif
                 {
                 reinterpret_cast<uint2*>(yo + 0 * 64)[c.hf] = uint2{r.ph[0] & vbits, r.ph[1] & vbits};
-                reinterpret_cast<uint2*>(yo + 1 * 64)[c.hf] = uint2{r.pm[0] & vbits, r.pm[1] & vbits};
-                reinterpret_cast<uint2*>(yo + 2 * 64)[c.hf] = uint2{r.pl[0] & vbits, r.pl[1] & vbits};
+                reinterpret_cast<uint2*>(yo + 1 * 64)[c.hf] = uint2{r.pl[0] & vbits, r.pl[1] & vbits};
                 }
             }
             return;
         }
-        const int pu = piece < 12 ? piece : piece - 1;   // 0..23
-        const int u = pu / 6, st = pu % 6;
-        if (st == 0) r.ig[u] = snn_sigmoid(pin(acc[u]));
-        else if (st == 1) r.gg[u] = snn_tanh(pin(acc[8 + u]));
-        else if (st == 2) r.fg[u] = snn_sigmoid(pin(acc[4 + u]));
+        const int k = piece >> 3, st = piece & 7;
+        if (st == 0) r.di[k] = one + exp2_2(pin(gate(0, k)));                    // 1 + e^-i
+        else if (st == 1) r.dg[k] = one + exp2_2(pin(gate(2, k)));               // 1 + e^2g
+        else if (st == 2) r.df[k] = one + exp2_2(pin(gate(1, k)));               // 1 + e^-f
         else if (st == 3) {
-            const float cn = fmaf(pin(r.fg[u]), cst[qa][u], __fmul_rn(r.ig[u], r.gg[u]));   // as the one-tile kernel
-            r.tc[u] = snn_tanh(cn);
-            cst[qa][u] = lane_select(vmask, cn, cst[qa][u]);
-        } else if (st == 4) r.og[u] = snn_sigmoid(pin(acc[12 + u]));
-        else {
-            const float hv = pin(r.og[u]) * r.tc[u];
-            hst[qa][u] = lane_select(vmask, hv, hst[qa][u]);
-            if (LAST) hsum[qa][u] += lane_select(vmask, hv, 0.0f);
+            r.ig[k] = rcp_2(pin(r.di[k]));
+            r.gg[k] = fma_2(mtwo, rcp_2(r.dg[k]), one);                          // tanh(g)
+        } else if (st == 4) {
+            const f2 cn = fma_2(rcp_2(pin(r.df[k])), cst[qa][k], r.ig[k] * r.gg[k]);
+            r.dc[k] = cn * f2{2.88539008177792681f, 2.88539008177792681f};
+            cst[qa][k] = f2{lane_select(vmask, cn.x, cst[qa][k].x), lane_select(vmask, cn.y, cst[qa][k].y)};
+        } else if (st == 5) {
+            r.dc[k] = one + exp2_2(pin(r.dc[k]));                                // 1 + e^2c
+            r.dq[k] = one + exp2_2(gate(3, k));                                  // 1 + e^-o
+        } else if (st == 6) {
+            const f2 hv = rcp_2(pin(r.dq[k])) * fma_2(mtwo, rcp_2(r.dc[k]), one);   // sigmoid(o) tanh(c)
+            hst[qa][k] = f2{lane_select(vmask, hv.x, hst[qa][k].x), lane_select(vmask, hv.y, hst[qa][k].y)};
+            if (LAST) hsum[qa][k] += f2{lane_select(vmask, hv.x, 0.0f), lane_select(vmask, hv.y, 0.0f)};
+        } else {   // split2 of the pair
+            const f2 hv = pin(hst[qa][k]);
+            const unsigned int hi = cvt_pk_f16(hv.x, hv.y);
+            const f2 hf = f2{(float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu)),
+                             (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16))};
+            const f2 rs = (hv - hf) * f2{SNN_H2_LO_SCALE, SNN_H2_LO_SCALE};
+            r.ph[k] = hi;
+            r.pl[k] = cvt_pk_f16(rs.x, rs.y);
         }
     };
-    // One pipeline phase: the MFMA chain of tile qc (into accc), with the cell update of tile qa (from acca, step ta)
-    // issued piecewise behind the MFMAs.  sched_barrier(0) pins the program order: nothing crosses it.
-    auto phase = [&](int qc, f32x16& accc, bool do_act, int qa, int ta, const f32x16& acca) {
+    // One pipeline phase: the MFMA chains of tile qc (into mc / xc), with the cell update of tile qa (from ma / xa, step
+    // ta) issued piecewise behind the MFMAs.  sched_barrier(0) pins the program order: nothing crosses it.
+    auto phase = [&](int qc, f32x16& mc, f32x16& xc, bool do_act, int qa, int ta, const f32x16& ma, const f32x16& xa) {
         const unsigned long long vmask = __builtin_amdgcn_ballot_w64(ta < len[qa]);
         const unsigned int vbits = ta < len[qa] ? 0xffffffffu : 0u;
         ActRegs r;
-        bf16x8 bv[NB][3];
-        const u32x4* xc = xin + qc * XS + c.lane;
-        const u32x4* hc = hb + qc * HS + c.lane;
+        f16x8 bv[NB][2];
+        const u32x4* xs = xin + qc * XS + c.lane;
+        const u32x4* hs = hb + qc * HS + c.lane;
         auto bload = [&](int b) {
-            const u32x4* src = b < XB ? xc + b * BLK_U4 : hc + (b - XB) * BLK_U4;
+            const u32x4* src = b < XB ? xs + b * BLK_U4 : hs + (b - XB) * BLK_U4;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bv[b][q] = __builtin_bit_cast(bf16x8, src[q * 64]);
+            for (int q = 0; q < 2; ++q) bv[b][q] = __builtin_bit_cast(f16x8, src[q * 64]);
         };
         bload(0);
-        accc = *binit_p;
+        mc = *binit_p;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (b + 1 < NB) bload(b + 1);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-
-                // small terms first: (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi), as snn_forward_b3.hip
-                constexpr int WQ[6] = {1, 2, 0, 1, 0, 0}, BQ[6] = {1, 0, 2, 0, 1, 0};
-#if defined(SNN_ABL_NOMFMA)     // timing ablations only: one / three products per block instead of six
-                if (j == 0)
-#elif defined(SNN_ABL_HALFMFMA)
-                if (j >= 3)
+            for (int j = 0; j < 3; ++j) {
+#if defined(SNN_ABL_NOMFMA)     // timing ablation only: one product per block instead of three
+                if (j == 2 || b == 0)
 #endif
-                accc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[b][WQ[j]], bv[b][BQ[j]], accc, 0, 0, 0);
+                {
+                if (j == 0) {
+                    const f32x16 zero = {0};
+                    xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[b][0], bv[b][1], b == 0 ? zero : xc, 0, 0, 0);   // hi * lo
+                } else if (j == 1) xc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[b][1], bv[b][0], xc, 0, 0, 0);   // lo * hi
+                else mc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[b][0], bv[b][0], mc, 0, 0, 0);                 // hi * hi
+                }
                 if (do_act) {
-                    const int m = b * 6 + j;
+                    const int m = b * 3 + j;
                     const int lo = (m * NPIECE + NM - 1) / NM, hi = ((m + 1) * NPIECE + NM - 1) / NM;
 #pragma unroll
-                    for (int pc = lo; pc < hi; ++pc) act_piece(qa, ta, acca, r, vmask, vbits, pc);
+                    for (int pc = lo; pc < hi; ++pc) act_piece(qa, ta, ma, xa, r, vmask, vbits, pc);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    auto act_only = [&](int qa, int ta, const f32x16& acca) {
+    auto act_only = [&](int qa, int ta, const f32x16& ma, const f32x16& xa) {
         const unsigned long long vmask = __builtin_amdgcn_ballot_w64(ta < len[qa]);
         const unsigned int vbits = ta < len[qa] ? 0xffffffffu : 0u;
         ActRegs r;
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) act_piece(qa, ta, acca, r, vmask, vbits, pc);
+        for (int pc = 0; pc < NPIECE; ++pc) act_piece(qa, ta, ma, xa, r, vmask, vbits, pc);
     };
 
-    // ---- prologue: x(t0) of both tiles, h = 0, request x(t1), first chain of tile 0
+    // ---- prologue: x(t0) of both tiles, h = 0, request x(t1), first chains of tile 0
     const int dt = d == 0 ? 1 : -1;
     const int t0 = d == 0 ? 0 : T - 1;
     u32x4 pre0[NPT], pre1[NPT];
@@ -244,36 +256,36 @@ __device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, i
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                reinterpret_cast<uint2*>(hb + q * HS + (hblk * 3 + k) * 64 + hlane)[c.hf] = uint2{0u, 0u};
+            for (int k = 0; k < 2; ++k)
+                reinterpret_cast<uint2*>(hb + q * HS + (hblk * 2 + k) * 64 + hlane)[c.hf] = uint2{0u, 0u};
         const int t1 = T > 1 ? t0 + dt : t0;
         load_step(0, t1, pre0);
         load_step(1, t1, pre1);
     }
     lds_barrier();
-    f32x16 acc0, acc1;
-    phase(0, acc0, false, 0, 0, acc0);
+    f32x16 m0, x0, m1, x1;
+    phase(0, m0, x0, false, 0, 0, m0, x0);
     lds_barrier();   // every wave has read h0 = 0 before the first cell update overwrites it
 
     for (int step = 0; step + 1 < T; ++step) {
         const int t = t0 + dt * step;
         const int tnn = step + 2 < T ? t + 2 * dt : t + dt;
-        // phase I: chain of tile 1 (step t) || cell update of tile 0 (step t)
-        phase(1, acc1, true, 0, t, acc0);
+        // phase I: chains of tile 1 (step t) || cell update of tile 0 (step t)
+        phase(1, m1, x1, true, 0, t, m0, x0);
         store_step(0, pre0);          // x0(t + 1)
         load_step(0, tnn, pre0);
         lds_barrier();
-        // phase II: chain of tile 0 (step t + 1) || cell update of tile 1 (step t)
-        phase(0, acc0, true, 1, t, acc1);
+        // phase II: chains of tile 0 (step t + 1) || cell update of tile 1 (step t)
+        phase(0, m0, x0, true, 1, t, m1, x1);
         store_step(1, pre1);
         load_step(1, tnn, pre1);
         lds_barrier();
     }
     {   // last step
         const int t = t0 + dt * (T - 1);
-        phase(1, acc1, true, 0, t, acc0);
+        phase(1, m1, x1, true, 0, t, m0, x0);
         lds_barrier();   // tile 1's cell update overwrites the h image the other waves' chains may still be reading
-        act_only(1, t, acc1);
+        act_only(1, t, m1, x1);
     }
 
     // ---- head contribution of this phase (fp32, as lstm_fwd_kernel), tile by tile
@@ -288,10 +300,10 @@ __device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, i
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (y.pool == SNN_POOL_MEAN) {
-                    feat[u] = __fdiv_rn(hsum[q][u], (float)(len[q] > 0 ? len[q] : 1));
+                    feat[u] = __fdiv_rn(hsum[q][u >> 1][u & 1], (float)(len[q] > 0 ? len[q] : 1));
                     fidx[u] = d * H + j0 + u;
                 } else {
-                    feat[u] = hst[q][u];
+                    feat[u] = hst[q][u >> 1][u & 1];
                     fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
                 }
             }
@@ -317,7 +329,7 @@ __device__ __forceinline__ void b3p_phase(const FwdParams& p, const B3PCtx& c, i
 }
 
 template <int H, int XB0, int DIRS>
-__global__ void __launch_bounds__(H * 8, SNN_B3P_WAVES) lstm_fwd_b3p_kernel(const FwdParams p, const B3Offsets o)
+__global__ void __launch_bounds__(H * 8, SNN_H2_WAVES) lstm_fwd_h2_kernel(const FwdParams p, const B3Offsets o)
 {
     constexpr int NT = H * 8, NW = H / 8, HB = H / 16;
     constexpr int XB1 = DIRS * HB;
@@ -332,14 +344,16 @@ __global__ void __launch_bounds__(H * 8, SNN_B3P_WAVES) lstm_fwd_b3p_kernel(cons
     int* info = reinterpret_cast<int*>(bl + NW * 32);       // [B3_G][64]
     int* item_slot = info + B3_G * 64;
 
-    B3PCtx c;
+    H2Ctx c;
     c.tid = threadIdx.x;
     c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.lane = threadIdx.x & 63;
     c.cl = c.lane & 31;
     c.hf = c.lane >> 5;
     u32x4* ybase = reinterpret_cast<u32x4*>(p.yscratch) + (int64_t)blockIdx.x * p.nbuf * p.y_buf_floats / 4;
-    // work queues, one per XCD, with stealing: see snn_forward_b3.hip
+    // Work queues, one per XCD (workgroups are dispatched round-robin over the 8 XCDs, each with its own L2):
+    // queue x holds the tile groups x, x + 8, ... with all MC samples of a group adjacent, so the x image of a
+    // group is fetched into ONE L2 and shared by its S items.  An XCD that runs dry steals from the next queue.
     const int n_groups = (p.n_tiles + B3_G - 1) / B3_G;
     const int xcd = blockIdx.x & 7;
 
@@ -369,11 +383,11 @@ __global__ void __launch_bounds__(H * 8, SNN_B3P_WAVES) lstm_fwd_b3p_kernel(cons
                 for (int d = 0; d < DIRS; ++d) {
                     const int ld = l * DIRS + d;
                     if (l == 0) {
-                        if (last) b3p_phase<H, XB0, DIRS, true, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                        else b3p_phase<H, XB0, DIRS, true, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        if (last) h2_phase<H, XB0, DIRS, true, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else h2_phase<H, XB0, DIRS, true, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
                     } else {
-                        if (last) b3p_phase<H, XB1, DIRS, false, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                        else b3p_phase<H, XB1, DIRS, false, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        if (last) h2_phase<H, XB1, DIRS, false, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else h2_phase<H, XB1, DIRS, false, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
                     }
                 }
             }
@@ -404,12 +418,12 @@ __global__ void __launch_bounds__(H * 8, SNN_B3P_WAVES) lstm_fwd_b3p_kernel(cons
 
 // ---- registry hook used by snn_forward.hip -----------------------------------------------------------
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
-fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs)
+fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs)
 {
     if (H == 32 && dirs == 2) {
-        if (XB0 == 2) return lstm_fwd_b3p_kernel<32, 2, 2>;   // D <= 26 (buckets 24, 26)
-        if (XB0 == 3) return lstm_fwd_b3p_kernel<32, 3, 2>;   // D <= 48
-        if (XB0 == 5) return lstm_fwd_b3p_kernel<32, 5, 2>;   // D <= 78
+        if (XB0 == 2) return lstm_fwd_h2_kernel<32, 2, 2>;   // D <= 26 (buckets 24, 26)
+        if (XB0 == 3) return lstm_fwd_h2_kernel<32, 3, 2>;   // D <= 48
+        if (XB0 == 5) return lstm_fwd_h2_kernel<32, 5, 2>;   // D <= 78
     }
     return nullptr;
 }

@@ -118,8 +118,23 @@ __device__ __forceinline__ int64_t kernel_index3(const SnnLayout& y, const Tenso
     const int w = j >> 3, r = gate * 8 + (j & 7);
     const int k = g.kind == 0 ? col : 16 * y.XB[l] + col;
     const int b = k >> 4, lane = ((k >> 3) & 1) * 32 + r, e = k & 7;
-    return y.k_A[g.ld] * 2 + ((((int64_t)w * y.NB[l] + b) * 3) * 64 + lane) * 8 + e;
+    return y.k_A[g.ld] * 2 + ((((int64_t)w * y.NB[l] + b) * y.NPC) * 64 + lane) * 8 + e;
 }
+// precision 2: x = hi + lo * 2^-11 with hi = fp16(x) and lo = fp16((x - hi) * 2^11): the remainder is exact in fp32
+// and has at most 12 significant bits, so the pair carries x to one fp32 ulp at worst (exactly for 3 values in 4).
+// fp16 subnormals are produced by the conversion and honoured by v_mfma_f32_32x32x16_f16 on gfx950
+// (microbench/f16_denorm_probe.hip), so small values need no special case; |x| >= 65520 has no fp16 and gives
+// inf - inf = NaN downstream (inputs are normalised features).
+#define SNN_H2_LO_SCALE 2048.0f
+#define SNN_H2_LO_INV 4.8828125e-04f
+__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * SNN_H2_LO_SCALE);
+}
+// exp2 factor folded into the weight rows and biases of gate `gate` (0 i, 1 f, 2 g, 3 o) in precision 2:
+// sigmoid(a) = 1 / (1 + 2^(-a log2 e)), tanh(a) = 1 - 2 / (1 + 2^(2 a log2 e))
+__device__ __forceinline__ float h2_gate_scale(int gate) { return gate == 2 ? 2.88539008177792681f : -1.44269504088896341f; }
 // x = hi + mid + lo to 2^-27 relative, each piece a bf16 (round-to-nearest-even; the two remainders are exact in fp32)
 __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
 {

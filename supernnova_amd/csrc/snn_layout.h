@@ -39,7 +39,11 @@ struct SnnLayout {
     //   [NW][NB][3 pieces][64 lanes][8 bf16]   lane (r = lane & 31, khalf = lane >> 5) holds
     //   Wcat3[row(w, r)][16 b + 8 khalf + e], Wcat3 = [w_ih | zero pad to 16*XB | w_hh], NB = XB + H/16;
     // k_A / k_bias / k_head_* / PK then describe that image (in 4-byte words); bias and head stay fp32.
+    // precision 2 (fp16 x 2 pieces, snn_forward_h2.hip): same image with 2 pieces of 8 fp16 per lane, hi = fp16(v),
+    //   lo = fp16((v - hi) * 2^11); the weight rows are pre-scaled by the gate's exp2 factor (-log2 e for i, f, o;
+    //   2 log2 e for g), see snn_split2_scale.
     int prec;
+    int NPC;   // pieces per value: 3 (precision 1), 2 (precision 2)
     int XB[SNN_MAX_LAYERS], NB[SNN_MAX_LAYERS];
 };
 
@@ -58,9 +62,10 @@ static inline int snn_kki0_bucket(int D)
 static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool, int prec = 0)
 {
     if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1 || prec < 0 ||
-        prec > 1 || (prec == 1 && (H % 16) != 0))
+        prec > 2 || (prec >= 1 && (H % 16) != 0))
         return -1;
     y->prec = prec;
+    y->NPC = prec == 2 ? 2 : 3;
     y->D = D; y->H = H; y->L = L; y->dirs = bidir ? 2 : 1; y->C = C; y->pool = pool;
     y->F = pool == 0 ? y->dirs * H : y->dirs * H * L;
     y->Dp = 2 * snn_kki0_bucket(D);
@@ -78,7 +83,7 @@ static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, 
             y->c_whh[ld] = c; c += (int64_t)4 * H * H;
             y->c_bih[ld] = c; c += 4 * H;
             y->c_bhh[ld] = c; c += 4 * H;
-            y->k_A[ld] = k; k += prec == 0 ? (int64_t)y->NW * y->KK[l] * 64 : (int64_t)y->NW * y->NB[l] * 3 * 64 * 4;
+            y->k_A[ld] = k; k += prec == 0 ? (int64_t)y->NW * y->KK[l] * 64 : (int64_t)y->NW * y->NB[l] * y->NPC * 64 * 4;
             y->k_bias[ld] = k; k += (int64_t)2 * y->NW * 32;
         }
     }

@@ -39,13 +39,13 @@ class Config:
     bidirectional: bool = True
     nb_classes: int = 2
     pool: str = "mean"
-    precision: str = "f32"      # "f32" | "bf16x3" (include/snn_hip.h: SNN_PREC_*; inference only)
+    precision: str = "f32"      # "f32" | "bf16x3" | "f16x2" (include/snn_hip.h: SNN_PREC_*; the last two inference only)
 
     @property
     def c(self):
         return L.SnnCfg(self.input_size, self.hidden_size, self.num_layers, int(bool(self.bidirectional)),
                         self.nb_classes, L.SNN_POOL_MEAN if self.pool == "mean" else L.SNN_POOL_STANDARD,
-                        L.SNN_PREC_BF16X3 if self.precision == "bf16x3" else L.SNN_PREC_F32)
+                        {"f32": L.SNN_PREC_F32, "bf16x3": L.SNN_PREC_BF16X3, "f16x2": L.SNN_PREC_F16X2}[self.precision])
 
     def with_precision(self, precision):
         from dataclasses import replace

@@ -79,7 +79,8 @@ class _HipRNN(nn.Module):
 
     draws = "philox"
     # arithmetic of the gate products in eval-mode forwards without dropout masks (VanillaRNN, BayesianRNN):
-    # "f32" (exact fp32, default) or "bf16x3" (six bf16 piece products per fp32 product; include/snn_hip.h)
+    # "f32" (exact fp32, default), "bf16x3" (six bf16 piece products per fp32 product) or "f16x2" (three fp16 piece
+    # products; include/snn_hip.h)
     inference_precision = "f32"
 
     def infer_cfg(self, masked=False):

@@ -263,17 +263,20 @@ def test_unsupported_shapes_fail_loudly():
                 _lib.check(_lib.load().snn_lstm_forward_workspace_bytes(__import__("ctypes").byref(cfg.c), 10), "ws")
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
                                             (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
-                                            (42, 2, "mean", 2, 50, 12), (78, 14, "mean", 2, 40, 30)])
-def test_bf16x3_precision_vs_oracle(D, C, pool, L, N, T):
-    """SNN_PREC_BF16X3: every fp32 product rebuilt from six bf16 piece products on the bf16 matrix pipe.  Same
-    parity bar as the fp32 kernels (logits 5e-6 absolute, probabilities 1e-5 relative) against the C oracle, and
-    an error against the float64 oracle of the same size as the fp32 kernel's own."""
+                                            (42, 2, "mean", 2, 50, 12), (78, 14, "mean", 2, 40, 30),
+                                            (24, 2, "mean", 2, 21, 40)])
+def test_split_precision_vs_oracle(prec, D, C, pool, L, N, T):
+    """SNN_PREC_BF16X3: every fp32 product rebuilt from six bf16 piece products on the bf16 matrix pipe;
+    SNN_PREC_F16X2: from three fp16 piece products.  Same parity bar as the fp32 kernels (logits 5e-6 absolute,
+    probabilities 1e-5 relative) against the C oracle, and an error against the float64 oracle of the same size
+    as the fp32 kernel's own."""
     E = _eng()
     H, S = 32, 2
     cfg32 = E.Config(D, H, L, True, C, pool)
-    cfg = cfg32.with_precision("bf16x3")
+    cfg = cfg32.with_precision(prec)
     assert cfg.supported()
     ocfg = oracle.make_cfg(D, H, L, True, C, pool)
     w = _random_model(cfg, 31, 0.15)
@@ -288,13 +291,14 @@ def test_bf16x3_precision_vs_oracle(D, C, pool, L, N, T):
     assert e3 < 3 * e32 + 2e-7, (e3, e32)
 
 
-def test_bf16x3_large_batch_properties():
-    """bf16x3 at a size with many tile groups spread over the per-XCD queues: shuffling the curves permutes the
-    outputs bit-for-bit, and the probabilities agree with the exact-fp32 launch to the parity bar."""
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_split_precision_large_batch_properties(prec):
+    """bf16x3 / f16x2 at a size with many tile groups spread over the per-XCD queues: shuffling the curves permutes
+    the outputs bit-for-bit, and the probabilities agree with the exact-fp32 launch to the parity bar."""
     E = _eng()
     D, H, C, S, N, T = 24, 32, 2, 3, 9001, 40
     cfg32 = E.Config(D, H, 2, True, C, "mean")
-    cfg = cfg32.with_precision("bf16x3")
+    cfg = cfg32.with_precision(prec)
     g = np.random.default_rng(18)
     mu = g.uniform(-0.3, 0.3, cfg.P).astype(np.float32)
     rho = g.uniform(-4, -2, cfg.P - C).astype(np.float32)
@@ -315,14 +319,15 @@ def test_bf16x3_large_batch_properties():
 @pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
                                             (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
                                             (24, 2, "mean", 2, 33, 1), (78, 14, "mean", 2, 161, 12)])
-def test_bf16x3_paired_kernel_matches_one_tile_kernel(D, C, pool, L, N, T):
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_split_precision_results_do_not_depend_on_tiling(prec, D, C, pool, L, N, T):
     """bf16x3 over more than one tile runs the two-tiles-per-workgroup pipeline (snn_forward_b3p.hip); a batch of
     <= 32 curves runs the one-tile kernel (snn_forward_b3.hip).  Same products in the same order: the same curves
     must give bit-identical results through both (odd tile counts, groups of 1..4 tiles, partners of different
-    length, 1..3 layers, both poolings)."""
+    length, 1..3 layers, both poolings).  f16x2 has one kernel (snn_forward_h2.hip) and the same property."""
     E = _eng()
     H, S = 32, 2
-    cfg = E.Config(D, H, L, True, C, pool).with_precision("bf16x3")
+    cfg = E.Config(D, H, L, True, C, pool).with_precision(prec)
     ocfg = oracle.make_cfg(D, H, L, True, C, pool)
     w = _random_model(cfg, 33, 0.15)
     x, lengths = make_curves(34, N, T, D, min_len=1)

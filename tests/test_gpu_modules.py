@@ -135,16 +135,18 @@ def test_sampled_mode_statistics(model):
     assert np.array_equal(a, b) and not np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("fast", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("model", ["vanilla", "bayesian"])
-def test_inference_precision_bf16x3_through_the_module_api(model):
-    """`rnn.inference_precision = "bf16x3"`: eval-mode forward, forward_mc and predict_mc run the split-bf16 kernels
-    and agree with the exact-fp32 launch of the same draws to the parity bar; training is unaffected."""
+def test_inference_precision_through_the_module_api(model, fast):
+    """`rnn.inference_precision = "bf16x3" | "f16x2"`: eval-mode forward, forward_mc and predict_mc run the
+    split-precision kernels and agree with the reference fixture and with the exact-fp32 launch of the same draws to
+    the parity bar; training is unaffected."""
     from supernnova_amd.validation.validate_rnn import predict_mc
     g = load_golden("g1_vanilla_mean" if model == "vanilla" else "g3_bayesian_mean")
     rnn = _model(model, g["sd"], 24)
     rnn.draws = "host"
     outs = {}
-    for prec in ("f32", "bf16x3"):
+    for prec in ("f32", fast):
         rnn.inference_precision = prec
         with torch.no_grad():
             torch.manual_seed(2000)
@@ -155,7 +157,7 @@ def test_inference_precision_bf16x3_through_the_module_api(model):
             torch.manual_seed(2000)
             c = predict_mc(rnn, curves, 3).cpu().numpy()
         outs[prec] = (a, b, c)
-    _close(torch.from_numpy(outs["bf16x3"][0]), g["logits"][0] if model == "bayesian" else g["logits"])
-    for u, v in zip(outs["f32"], outs["bf16x3"]):
-        assert rel_err(softmax_np(u) if u is outs["f32"][0] else u, softmax_np(v) if v is outs["bf16x3"][0] else v) < PROB_RTOL
-    np.testing.assert_allclose(outs["bf16x3"][1], outs["bf16x3"][2], rtol=0, atol=0)   # same launch, two entry points
+    _close(torch.from_numpy(outs[fast][0]), g["logits"][0] if model == "bayesian" else g["logits"])
+    for u, v in zip(outs["f32"], outs[fast]):
+        assert rel_err(softmax_np(u) if u is outs["f32"][0] else u, softmax_np(v) if v is outs[fast][0] else v) < PROB_RTOL
+    np.testing.assert_allclose(outs[fast][1], outs[fast][2], rtol=0, atol=0)   # same launch, two entry points
