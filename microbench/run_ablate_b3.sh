@@ -6,6 +6,6 @@ out=gpurun_out/ablate_b3.txt
 for f in variants/*.so; do
   v=$(basename $f .so)
   echo "== $v" >> $out
-  SNN_BENCH_NOCHECK=1 SNN_HIP_LIB=$PWD/$f timeout -k 10 120 python bench.py --precision bf16x3 --curves 400000 --cpu-curves 0 --steps 2 --warmup 1 2>&1 | grep -o '"kernel_ms": [0-9.]*' >> $out || exit 1
+  SNN_BENCH_NOCHECK=1 SNN_HIP_LIB=$PWD/$f timeout -k 10 120 python bench.py --precision ${PREC:-bf16x3} --curves 400000 --cpu-curves 0 --steps 2 --warmup 1 2>&1 | grep -o '"kernel_ms": [0-9.]*' >> $out || exit 1
 done
 cat $out

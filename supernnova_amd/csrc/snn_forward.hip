@@ -443,7 +443,7 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
 {
     const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
     g->threads = y.H * 8;
-    const int G = 4;   // B3_G of snn_forward_b3.hip: tiles per work item
+    const int G = y.prec == 2 ? SNN_H2_G : 4;   // tiles per work item (B3_G of the kernels)
     g->lds = (size_t)(2 * XBM + 2 * HB) * y.NPC * 64 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
     int dev = 0, cus = 0, per_cu = 0;
@@ -496,7 +496,8 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     o.k_head_w = y.k_head_w;
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipMemsetAsync(workspace, 0, 1024, st));
-    const int64_t n_items = (int64_t)((n_tiles + 3) / 4) * n_samples;
+    const int G = y.prec == 2 ? SNN_H2_G : 4;
+    const int64_t n_items = (int64_t)((n_tiles + G - 1) / G) * n_samples;
     hipLaunchKernelGGL(fn, dim3((int)std::min<int64_t>(g.grid, n_items)), dim3(g.threads), g.lds, st, p, o);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;

@@ -30,7 +30,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #endif
 
 constexpr int BLK_U4 = 2 * 64;   // uint4 (16-byte) words of one K=16 block: 2 pieces x 64 lanes
-constexpr int B3_G = 4;          // tiles of one work item (two pairs)
+constexpr int B3_G = SNN_H2_G;   // tiles of one work item (snn_kernels.h)
+static_assert(B3_G % 2 == 0, "a work item is a whole number of tile pairs (the y slab has B3_G tile slots)");
 
 __device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
 {

@@ -167,6 +167,11 @@ __host__ __device__ inline int64_t tape_tile_floats(int H, int n_ld, int max_T, 
 }
 
 // ---- forward kernel parameters (snn_forward.hip, snn_forward_big.hip) ---------
+// tiles of one work item of the fp16 x 2 forward kernel (one pair): the layer-0 output of the items in flight
+// (2 workgroups x 256 CUs x 2 tiles x T x 8 KB) then fits the 256 MB Infinity Cache instead of streaming through HBM
+#ifndef SNN_H2_G
+#define SNN_H2_G 2
+#endif
 // weight-image offsets of the bf16 x 3 forward kernel (4-byte words from the start of a weight set)
 struct B3Offsets { int64_t k_A[SNN_MAX_LD], k_bias[SNN_MAX_LD], k_head_w; };
 
