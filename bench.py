@@ -118,9 +118,11 @@ def main():
     ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--max-len", type=int, default=40)
-    ap.add_argument("--workload", choices=["des", "elasticc"], default="des",
+    ap.add_argument("--workload", choices=["des", "elasticc", "variational"], default="des",
                     help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
-                         "(H=128, 6 filters + redshift, 14 classes, 300-step sequences) -- a secondary measurement")
+                         "(H=128, 6 filters + redshift, 14 classes, 300-step sequences); variational: configs[1] "
+                         "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des) -- the last two "
+                         "are secondary measurements")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
                     help="f32: every gate product in fp32 (default); bf16x3 / f16x2: each fp32 product rebuilt from six "
@@ -141,6 +143,9 @@ def main():
     from supernnova_amd import engine as E
 
     big = args.workload == "elasticc"
+    var = args.workload == "variational"
+    if var and args.precision != "f32":
+        raise SystemExit("the masked (variational) kernels are fp32 only")
     if big:
         cfg = E.Config(78, 128, 2, True, 14, "mean")
         if args.curves == 1_250_000:
@@ -157,6 +162,11 @@ def main():
         lengths.fill_(args.max_len)      # exactly 300 steps for config 5
     lengths_host = lengths.cpu().numpy()
     prior = E.Prior()
+    if var:   # torch.nn.LSTM default init U(+-1/sqrt(H)); one weight image shared by all samples
+        gw = torch.Generator(device="cpu")
+        gw.manual_seed(0)
+        k = 1.0 / np.sqrt(cfg.hidden_size)
+        w_var = E.prepare_weights(cfg, ((torch.rand(cfg.P, generator=gw) * 2 - 1) * k).to(dev))
     torch.cuda.synchronize()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -165,10 +175,16 @@ def main():
     def step(i, timed):
         plan = E.Plan(cfg, lengths_host, dev)
         xp = E.pack_x(cfg, plan, x)
-        wk, kl = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i * S)
+        if var:
+            wk, kl = w_var, torch.zeros(1, device=dev)
+            masks = E.Masks(mode=2, which=0xF, dropout=0.05, seed=1234, offset=i * S)
+        else:
+            wk, kl = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i * S)
+            masks = None
         if timed:
             ev[0].record()
-        _, probs = E.lstm_forward(cfg, plan, xp, wk, S, want_logits=False, want_probs=True, sample_major=False)
+        _, probs = E.lstm_forward(cfg, plan, xp, wk, S, masks=masks, want_logits=False, want_probs=True,
+                                  sample_major=False)
         if timed:
             ev[1].record()
         return probs, kl
@@ -203,7 +219,8 @@ def main():
         achieved = fl / (k_ms * 1e-3) / 1e12
         b3 = args.precision != "f32"
         npr = 6 if args.precision == "bf16x3" else 3     # piece products per fp32 product
-        peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else "lstm_fwd_pair_kernel<32,12,2>")
+        peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else
+                                              "lstm_fwd_kernel<32,12,2,masked>" if var else "lstm_fwd_pair_kernel<32,12,2>")
         if b3:
             # executed 16-bit MFMA FLOPs: 6 (bf16x3) / 3 (f16x2) piece products per fp32 product, K padded to blocks of 16
             H, Dp16 = cfg.hidden_size, -(-cfg.input_size // 16) * 16
@@ -214,12 +231,13 @@ def main():
         traffic = None   # PMC bytes per launch of this workload, from the committed rocprofv3 passes (profiles/)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
-            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3:
+            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3 and not var:
                 traffic = tj["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
-            "metric": "light curves/s classified, BayesianRNN 50 MC samples",
+            "metric": ("light curves/s classified, VariationalRNN 50 MC samples" if var else
+                       "light curves/s classified, BayesianRNN 50 MC samples"),
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -228,6 +246,9 @@ def main():
             "config": {"workload": (f"BayesianRNN (BBB) LSTM 128x2 bidirectional, mean pooling, D=78 (6 filters + redshift), "
                                     f"C=14, S={S} MC samples, {args.max_len}-step sequences, {N} light curves per GPU "
                                     "(configs[4], ELAsTiCC-like)") if big else
+                                   ("VariationalRNN (MC dropout p=0.05, Philox masks) LSTM 32x2 bidirectional, mean "
+                                    f"pooling, D=24 (4 filters), C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
+                                    f"{N} light curves per GPU (configs[1])") if var else
                                    ("BayesianRNN (BBB) LSTM 32x2 bidirectional, mean pooling, D=24 (4 filters), "
                                     f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
@@ -239,7 +260,7 @@ def main():
         }
         if b3:
             out["roofline"]["fp32_equivalent_tflops"] = achieved_f32eq   # algorithmic FLOPs / kernel time
-        if args.cpu_curves > 0 and world == 1:
+        if args.cpu_curves > 0 and world == 1 and not var:
             n_cpu = min(args.cpu_curves, N)
             v, secs = cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu)
             out["cpu_baseline"] = {"value": v, "unit": "light curves/s", "cores": torch.get_num_threads(),

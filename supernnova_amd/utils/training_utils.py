@@ -3,9 +3,13 @@
   get_optimizer    :354-371
   get_data_batch   :374-481   host batching -> (packed, X_tensor, target, idxs_rev_sort)
   eval_step        :528-544
+  get_evaluation_metrics :609-707, get_loss_string :710-736, save_training_results :739-769, StopOnPlateau :847-911
   unnormalize_arr  :89-124    (needed by the 'sin' OOD transform)
-Data loading (HDF5), plotting and metrics stay out of scope.
+Data loading (HDF5) and plotting stay out of scope.
 """
+import json
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -133,3 +137,101 @@ def eval_step(rnn, packed_tensor):
     """Forward only, eval mode (training_utils.py:528-544)."""
     rnn.eval()
     return rnn(packed_tensor)
+
+
+def get_evaluation_metrics(settings, list_data, model, sample_size=None):
+    """AUC / accuracy / log-loss (/ mean KL) of `model` over `list_data`, batch by batch in eval mode -- one
+    stochastic forward per batch for the variational and Bayesian models, as the reference
+    (training_utils.py:609-707; its SWAG branch is out of scope).  Consumes numpy's global RNG for the
+    batch subsample exactly where the reference does."""
+    from sklearn import metrics
+    n = len(list_data)
+    batches = np.array_split(np.arange(n), n // min(n // 2, settings.batch_size))
+    if sample_size:
+        pick = np.random.permutation(len(batches))[: sample_size // min(sample_size // 2, settings.batch_size)]
+        batches = [batches[i] for i in pick]
+    preds, targets, kls = [], [], []
+    keep = settings.random_length
+    for idxs in batches:
+        settings.random_length = False                     # full light curves for evaluation (:641-646)
+        try:
+            packed, _, target, rev = get_data_batch(list_data, idxs, settings)
+        finally:
+            settings.random_length = keep
+        with torch.no_grad():
+            out = eval_step(model, packed)
+        if isinstance(model, BayesianRNN):
+            kls.append(float(model.kl.detach()))
+        preds.append(torch.softmax(out, dim=1).cpu().numpy()[rev])
+        targets.append(target.cpu().numpy()[rev])
+    preds, targets = np.concatenate(preds), np.concatenate(targets)
+    if not np.isfinite(preds).all():
+        raise FloatingPointError("non-finite class probabilities during evaluation")
+    auc = None
+    if settings.nb_classes == 2 and len(set(targets.tolist())) > 1:
+        auc = metrics.roc_auc_score(targets, preds[:, 1])
+    one_hot = np.zeros((len(targets), settings.nb_classes))
+    one_hot[np.arange(len(targets)), targets] = 1
+    d = {"AUC": auc, "Acc": metrics.accuracy_score(targets, preds.argmax(1)), "loss": metrics.log_loss(one_hot, preds)}
+    if kls:
+        d["KL"] = float(np.mean(kls))
+    return d
+
+
+def get_loss_string(d_losses_train, d_losses_val):
+    """Progress string `AUC/Acc/loss[/KL] [T]: ... [V]: ...` (training_utils.py:710-736)."""
+    fmt = lambda d: "/".join("NA" if (v is None or k == "epoch") else f"{v:.3g}" for k, v in d.items())
+    return "/".join(d_losses_train.keys()) + " [T]: " + fmt(d_losses_train) + " [V]: " + fmt(d_losses_val)
+
+
+def save_training_results(settings, d_monitor, training_time):
+    """Best validation metrics + wall time into rnn_dir/training_log.json, keyed by the model name
+    (training_utils.py:739-769)."""
+    res = {"training_time": training_time}
+    for key in ("AUC", "Acc"):
+        if key == "AUC" and settings.nb_classes > 2:
+            res[key] = -1
+        else:
+            res[key] = max(d_monitor[key]) if None not in d_monitor[key] else None
+    res["loss"] = min(d_monitor["loss"])
+    res["data_types_training"] = np.array2string(np.asarray(getattr(settings, "data_types_training", [])))
+    path = os.path.join(str(settings.rnn_dir), "training_log.json")
+    try:
+        with open(path) as f:
+            log = json.load(f)
+    except (OSError, ValueError):
+        log = {}
+    log[settings.pytorch_model_name] = res
+    with open(path, "w") as f:
+        json.dump(log, f)
+
+
+class StopOnPlateau:
+    """Plateau detector on a metric (training_utils.py:847-911): once more than 10 values are in, a standard
+    deviation of the last 10 below 5e-4 is a plateau; with `reduce_lr_on_plateau` the optimizer's learning rate is
+    divided by 10 and training stops at the `max_learning_rate_reduction`-th reduction, without it training
+    stops at once.  `step` returns True to stop, False inside the window, None before it is full -- as the
+    reference, whose callers test `is True`."""
+
+    def __init__(self, patience=10, reduce_lr_on_plateau=False, max_learning_rate_reduction=3):
+        self.patience = patience
+        self.last_epoch = -1
+        self.list_metric = []
+        self.reduce_lr_on_plateau = reduce_lr_on_plateau
+        self.max_learning_rate_reduction = max_learning_rate_reduction
+        self.learning_rate_reduction = 0
+
+    def step(self, metric_value, optimizer=None, epoch=None):
+        self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+        self.list_metric.append(metric_value)
+        if len(self.list_metric) <= 10:
+            return None
+        self.list_metric = self.list_metric[-10:]
+        if np.std(self.list_metric) >= 0.0005:
+            return False
+        if optimizer is None or not self.reduce_lr_on_plateau:
+            return True
+        for group in optimizer.param_groups:
+            group["lr"] = group["lr"] / 10.0
+        self.learning_rate_reduction += 1
+        return True if self.learning_rate_reduction == self.max_learning_rate_reduction else None

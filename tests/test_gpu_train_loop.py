@@ -1,0 +1,81 @@
+"""GPU: the epoch loops of training/train_rnn.py around the HIP train step -- what the reference's own
+tests/test_rnn.py checks (the run completes and leaves its files), plus that training actually learns a
+separable synthetic problem and that get_evaluation_metrics agrees with metrics computed from a plain forward."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from test_host_logic import settings
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(n, seed, D=24):
+    g = np.random.default_rng(seed)
+    data = []
+    for i in range(n):
+        L = int(g.integers(5, 21))
+        y = int(g.integers(0, 2))
+        X = g.standard_normal((L, D)).astype(np.float32)
+        X[:, :4] += 1.2 * (2 * y - 1)                # class-dependent flux level
+        data.append((X, y, f"id{i}"))
+    return data
+
+
+def _settings(tmp_path, model, **kw):
+    feats = [f"f{i}" for i in range(4)]
+    return settings(model=model, use_cuda=True, batch_size=64, nb_epoch=4, monitor_interval=1, random_length=True,
+                    rnn_dir=str(tmp_path), pytorch_model_name=f"{model}_test", learning_rate=5e-3,
+                    training_features_to_normalize=feats, arr_norm=np.arange(12, dtype=np.float64).reshape(4, 3),
+                    data_types_training=np.array(["Ia", "nonIa"]), cyclic=False, cyclic_phases=[1, 2, 3], **kw)
+
+
+@pytest.mark.parametrize("model", ["vanilla", "variational", "bayesian"])
+def test_train_loop_learns_and_leaves_the_reference_files(tmp_path, model):
+    from supernnova_amd.training import train_rnn
+    from supernnova_amd.utils import training_utils as tu
+    np.random.seed(0)
+    torch.manual_seed(0)
+    train, val = _dataset(512, 1), _dataset(128, 2)
+    st = _settings(tmp_path, model)
+    if model == "bayesian":      # KL / (num_batches * batch_size) dominates the loss on a 512-curve set: slower start
+        st.nb_epoch = 16
+    rnn = train_rnn.train(st, train, val)
+    log = json.load(open(tmp_path / "training_log.json"))[st.pytorch_model_name]
+    assert log["Acc"] > 0.9 and log["AUC"] > 0.95 and log["training_time"] > 0
+    assert os.path.isfile(tmp_path / f"{st.pytorch_model_name}.pt") and os.path.isfile(tmp_path / "data_norm.json")
+    assert json.load(open(tmp_path / "data_norm.json"))["f1"] == {"min": 3.0, "mean": 4.0, "std": 5.0}
+    # the checkpoint is a plain state dict with the reference's keys, loadable into a fresh module
+    sd = torch.load(tmp_path / f"{st.pytorch_model_name}.pt", weights_only=True)
+    fresh = tu.get_model(st, 24).cuda()
+    fresh.load_state_dict(sd)
+    # get_evaluation_metrics vs metrics from one plain deterministic forward (vanilla: eval mode has no randomness)
+    if model == "vanilla":
+        m = tu.get_evaluation_metrics(st, val, fresh)
+        st.random_length = False
+        packed, _, target, rev = tu.get_data_batch(val, np.arange(len(val)), st)
+        with torch.no_grad():
+            pr = torch.softmax(tu.eval_step(fresh, packed), 1).cpu().numpy()
+        acc = float((pr.argmax(1) == target.cpu().numpy()).mean())
+        assert abs(m["Acc"] - acc) < 1e-12 and m["AUC"] > 0.95
+        nll = -np.log(pr[np.arange(len(val)), target.cpu().numpy()]).mean()
+        assert abs(m["loss"] - nll) < 1e-5
+    elif model == "bayesian":
+        assert "KL" in tu.get_evaluation_metrics(st, val, rnn)
+
+
+def test_lr_range_test_and_one_cycle(tmp_path):
+    from supernnova_amd.training import train_rnn
+    np.random.seed(1)
+    torch.manual_seed(1)
+    train, val = _dataset(640, 3), _dataset(128, 4)
+    st = _settings(tmp_path, "vanilla", )
+    lr = train_rnn.get_lr(st, train, val)
+    assert 1e-8 <= lr <= 10.0
+    st.cyclic = True
+    train_rnn.train(st, train, val)
+    assert os.path.isfile(tmp_path / "training_log.json")

@@ -157,3 +157,41 @@ def test_find_idx_and_predict_dict():
     d = vr.construct_predict_dict(5, 3, 2)
     assert d["all"].shape == (5, 3, 2) and "PEAKMJD-7" in d and "all_sin" in d and d["target"].dtype == np.int64
     assert "PEAKMJD" not in vr.construct_predict_dict(5, 1, 2, MFE=True)
+
+
+def test_plateau_loss_string_schedule_and_training_log(tmp_path):
+    """Host policies of the epoch loops (utils/training_utils.py:710-769, 847-911; training/train_rnn.py:112-122)."""
+    import json
+    from supernnova_amd.utils import training_utils as tu
+    from supernnova_amd.training import train_rnn
+
+    opt = SimpleNamespace(param_groups=[{"lr": 1e-3}])
+    p = tu.StopOnPlateau(reduce_lr_on_plateau=True)
+    outs = [p.step(0.9, opt) for _ in range(10)]
+    assert outs == [None] * 10 and opt.param_groups[0]["lr"] == 1e-3          # window not full yet
+    assert p.step(0.9, opt) is None and abs(opt.param_groups[0]["lr"] - 1e-4) < 1e-12   # 1st reduction
+    assert p.step(0.9, opt) is None                                             # 2nd
+    assert p.step(0.9, opt) is True and abs(opt.param_groups[0]["lr"] - 1e-6) < 1e-14   # 3rd: stop
+    q = tu.StopOnPlateau()
+    vals = [0.5 + 0.01 * i for i in range(11)]
+    assert [q.step(v) for v in vals][-1] is False                               # still improving
+    assert [q.step(0.6) for _ in range(10)][-1] is True                         # flat, no LR policy: stop
+
+    s = tu.get_loss_string({"AUC": None, "Acc": 0.91234, "loss": 0.3}, {"AUC": 0.95, "Acc": 0.9, "loss": 0.25})
+    assert s == "AUC/Acc/loss [T]: NA/0.912/0.3 [V]: 0.95/0.9/0.25"
+
+    ph = [5, 10, 15]
+    sched = [train_rnn.one_cycle_sched(e, 1e-4, 1e-3, ph) for e in (0, 5, 10, 15)]
+    np.testing.assert_allclose(sched, [1e-4, 1e-3, 1e-4, 1e-6], rtol=1e-12)
+
+    st = settings(rnn_dir=str(tmp_path), pytorch_model_name="m1", data_types_training=np.array(["Ia", "nonIa"]))
+    tu.save_training_results(st, {"AUC": [0.8, 0.9], "Acc": [0.7, 0.75], "loss": [0.5, 0.4]}, 12.5)
+    st.pytorch_model_name = "m2"
+    st.nb_classes = 3
+    tu.save_training_results(st, {"AUC": [None, None], "Acc": [0.5, 0.6], "loss": [0.9, 1.0]}, 1.0)
+    log = json.load(open(tmp_path / "training_log.json"))
+    assert log["m1"]["AUC"] == 0.9 and log["m1"]["Acc"] == 0.75 and log["m1"]["loss"] == 0.4
+    assert log["m1"]["training_time"] == 12.5 and log["m2"]["AUC"] == -1 and log["m2"]["loss"] == 0.9
+
+    with pytest.raises(ValueError):
+        train_rnn.train(settings())          # no data lists: the HDF5 reader is not part of the package
