@@ -76,6 +76,12 @@ typedef struct snn_cfg {
  *                  2^-25 RMS) on v_mfma_f32_32x32x16_f16.  Half the matrix work of BF16X3 at an error of about
  *                  twice fp32 rounding; same parity bar.  Requires |x| < 65504 (normalised features): a larger
  *                  input has no fp16 and yields NaN probabilities for its light curve.  Layout rules as BF16X3.
+ *                  Masks (variational dropout) are supported for input widths <= 48 with locked masks (mid_T = 1):
+ *                  the kernel applies the Bernoulli BITS of the input, W_hh-row and between-layer masks (mask value
+ *                  != 0) exactly, as ANDs on the fp16 pieces, and the CALLER folds their keep_scale = 1/(1-p) into
+ *                  the weights before snn_prepare_weights: W_ih of layer 0 (input mask), W_hh of the forward
+ *                  directions (W_hh row mask), W_ih of layers >= 1 (between-layer mask); the output mask is applied
+ *                  by value (supernnova_amd/modules.py: VariationalRNN._infer_weights).
  */
 #define SNN_PREC_F32 0
 #define SNN_PREC_BF16X3 1

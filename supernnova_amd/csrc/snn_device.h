@@ -77,11 +77,15 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t draw, uin
     float u1 = u01(r.x), u2 = u01(r.y);
     return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
 }
-// Bernoulli(keep) * keep_scale for (draw, stream, a, b)
+// Bernoulli(keep) * keep_scale for (draw, stream, a, b).  One Philox block serves the four elements b & ~3 .. b | 3
+// (b is the feature index in every caller), so a thread that needs several consecutive features of one curve
+// evaluates the block once (the compiler merges the identical calls).
 __device__ __forceinline__ float philox_mask(uint64_t seed, uint64_t draw, uint32_t stream, uint32_t a,
                                              uint32_t b, float keep_prob, float keep_scale)
 {
-    Philox4 r = philox4x32_10(a, b, (uint32_t)draw, stream, (uint32_t)seed,
+    Philox4 r = philox4x32_10(a, b >> 2, (uint32_t)draw, stream, (uint32_t)seed,
                               (uint32_t)(seed >> 32) ^ (uint32_t)(draw >> 32));
-    return ((r.x >> 8) * 5.9604644775390625e-08f) < keep_prob ? keep_scale : 0.0f;
+    const uint32_t sel = b & 3u;
+    const uint32_t v = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+    return ((v >> 8) * 5.9604644775390625e-08f) < keep_prob ? keep_scale : 0.0f;
 }

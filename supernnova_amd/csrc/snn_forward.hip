@@ -255,7 +255,7 @@ fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pai
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
 fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs);     // snn_forward_b3p.hip (same, two tiles per workgroup)
-fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs);      // snn_forward_h2.hip (SNN_PREC_F16X2)
+fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs, bool masked);   // snn_forward_h2.hip (SNN_PREC_F16X2)
 static const FwdEntry* find_fwd(const SnnLayout& y)
 {
     static thread_local FwdEntry ent;
@@ -278,7 +278,7 @@ extern "C" int snn_supported(const snn_cfg* cfg)
     SnnLayout y;
     if (snn_make_layout(cfg, &y)) return 0;
     if (y.prec == 1) return snn_b3_kernel(y.H, y.XB[0], y.dirs) != nullptr;
-    if (y.prec == 2) return snn_h2_kernel(y.H, y.XB[0], y.dirs) != nullptr;
+    if (y.prec == 2) return snn_h2_kernel(y.H, y.XB[0], y.dirs, false) != nullptr;
     return find_fwd(y) != nullptr;
 }
 
@@ -463,11 +463,19 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
 static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
                              const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles,
                              int32_t max_T, const float* wk, int64_t wk_sample_stride, int32_t n_samples,
-                             float* out_logits, float* out_probs, int64_t out_stride_sample, int64_t out_stride_curve,
-                             void* workspace, int64_t workspace_bytes, void* stream)
+                             const snn_masks* masks, float* out_logits, float* out_probs, int64_t out_stride_sample,
+                             int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream)
 {
-    fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
-    if (!fn) { snn_set_error("no split-precision forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    const bool masked = masks && masks->mode != SNN_MASK_NONE;
+    if (masked && (y.prec != 2 || masks->mid_T != 1)) {
+        snn_set_error("split-precision kernels: masks are implemented for SNN_PREC_F16X2 with locked (mid_T = 1) masks only");
+        return SNN_ERR_UNSUPPORTED;
+    }
+    fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs, masked) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
+    if (!fn) {
+        snn_set_error("no split-precision forward kernel for H=%d D=%d dirs=%d%s", y.H, y.D, y.dirs, masked ? " with masks" : "");
+        return SNN_ERR_UNSUPPORTED;
+    }
     if (y.prec == 1 && n_tiles > 1) {   // two tiles per workgroup, software-pipelined (snn_forward_b3p.hip); bit-identical results
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
         fwd_b3_kernel_t fp = no_pair ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs);
@@ -486,6 +494,8 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
     p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.n_samples = n_samples;
     p.wk = wk; p.wk_stride = wk_sample_stride;
+    rc = snn_masks_to_device(masks, max_T, &p.mk);
+    if (rc) return rc;
     p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
     p.counter = (unsigned int*)workspace;                 // 8 per-XCD queue heads, 64 bytes apart
     p.yscratch = (float*)((char*)workspace + 1024);
@@ -509,12 +519,13 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
     if (y.prec != 0) {
-        fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
+        fwd_b3_kernel_t fn = y.prec == 2 ? snn_h2_kernel(y.H, y.XB[0], y.dirs, false) : snn_b3_kernel(y.H, y.XB[0], y.dirs);
         if (!fn) { snn_set_error("no split-precision forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
         if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
         FwdGeom g, gp;
         rc = b3_geom(y, fn, max_T, &g);
-        if (fwd_b3_kernel_t fp = (rc || y.prec != 1) ? nullptr : snn_b3p_kernel(y.H, y.XB[0], y.dirs)) {
+        if (fwd_b3_kernel_t fp = (rc || y.prec != 1) ? (rc ? nullptr : snn_h2_kernel(y.H, y.XB[0], y.dirs, true))
+                                                     : snn_b3p_kernel(y.H, y.XB[0], y.dirs)) {
             rc = b3_geom(y, fp, max_T, &gp);
             if (!rc) g.ws_bytes = std::max(g.ws_bytes, gp.ws_bytes);
         }
@@ -577,8 +588,8 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
         snn_set_error("snn_lstm_forward: null pointer");
         return SNN_ERR_ARG;
     }
-    if (y.prec != 0 && (train || (masks && masks->mode != SNN_MASK_NONE))) {
-        snn_set_error("SNN_PREC_BF16X3 / SNN_PREC_F16X2 are implemented for un-masked inference only");
+    if (y.prec != 0 && train) {
+        snn_set_error("SNN_PREC_BF16X3 / SNN_PREC_F16X2 are inference-only");
         return SNN_ERR_UNSUPPORTED;
     }
     if (n_curves < 1 || n_tiles != (n_curves + SNN_TILE - 1) / SNN_TILE || max_T < 1 || n_samples < 1 ||
@@ -590,7 +601,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     if (y.prec != 0)
         return launch_forward_b3(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, wk_sample_stride,
-                                 n_samples, out_logits, out_probs, out_stride_sample, out_stride_curve, workspace,
+                                 n_samples, masks, out_logits, out_probs, out_stride_sample, out_stride_curve, workspace,
                                  workspace_bytes, stream);
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (train && (!tape || n_samples != 1 || tape_floats < tape_tile * n_tiles)) {

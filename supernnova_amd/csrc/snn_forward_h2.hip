@@ -55,7 +55,7 @@ struct H2Ctx {
     const float* wks;
 };
 
-template <int H, int XB, int DIRS, bool FIRST, bool LAST>
+template <int H, int XB, int DIRS, bool FIRST, bool LAST, bool MASKED>
 __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int n_live, int tile0, const int* info,
                                          int l, int d, int64_t k_A, int64_t k_bias, int64_t k_head_w, u32x4* xin,
                                          u32x4* hb, float* part, float* logit_all, float* bl, u32x4* ybase_all)
@@ -66,6 +66,11 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
     constexpr int XS = XB * BLK_U4, HS = HB * BLK_U4;               // LDS words of one tile's x / h image
     const FwdParams& y = p;
     const int ld = l * DIRS + d;
+    // Variational masks (MASKED): the kernel applies the Bernoulli BITS (mask value != 0) with ANDs on the fp16 pieces,
+    // which is exact; the 1/(1-p) factor of the input, W_hh-row and between-layer masks is folded into the weights by
+    // the caller (include/snn_hip.h, SNN_PREC_F16X2).  The output mask multiplies the pooled features in fp32.
+    const MaskP& mk = p.mk;
+    const bool masked = MASKED && mk.mode != SNN_MASK_NONE;
 
     // ---- weight pieces -> registers, shared by both tiles: wr[b][piece] = 8 fp16 (4 VGPRs)
     f16x8 wr[NB][2];
@@ -75,6 +80,15 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) wr[b][q] = __builtin_bit_cast(f16x8, A[(b * 2 + q) * 64]);
+    }
+    if (MASKED && masked && d == 0) {   // W_hh row mask, forward direction only (variational_rnn.py:45, 224-238)
+        const int r = c.lane & 31;      // this lane's A-operand row: gate r >> 3 of hidden unit 8w + (r & 7)
+        const unsigned int keep = mask_whh(mk, c.s, y.L, H, l, (r >> 3) * H + 8 * c.w + (r & 7)) != 0.0f ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int b = XB; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                wr[b][q] = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4, wr[b][q]) & keep);
     }
     if (c.cl < 16) {   // b_ih + b_hh in C/D register order (entry i: gate i >> 2), times the gate's exp2 factor
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
@@ -109,6 +123,45 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
     }
     __syncthreads();   // the previous pair's head reduction has finished with part / logit before this pair's staging
 
+    // mask bits of this pair: the between-layer mask of the lane's own 4 outputs (applied by the producer), and the
+    // input mask of the words this thread stages (8 features of one curve each); both locked over time
+    unsigned int ymask[2][2] = {{~0u, ~0u}, {~0u, ~0u}};
+    u32x4 xm[2][NPT];
+    if (MASKED) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool live = q == 0 || has1;
+            if (!LAST && masked) {
+                const int orig = live ? info[(2 * pr + q) * 64 + 32 + c.cl] : -1;
+                if (orig >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const bool b0 = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, orig, d * H + j0 + 2 * k) != 0.0f;
+                        const bool b1 = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, orig, d * H + j0 + 2 * k + 1) != 0.0f;
+                        ymask[q][k] = (b0 ? 0x0000ffffu : 0u) | (b1 ? 0xffff0000u : 0u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                xm[q][i] = u32x4{~0u, ~0u, ~0u, ~0u};
+                if (FIRST && masked) {
+                    const int f = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
+                    const int b = f / BLK_U4, lp = f & 63;
+                    const int orig = live ? info[(2 * pr + q) * 64 + 32 + (lp & 31)] : -1;
+                    if (orig >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = 16 * b + 8 * (lp >> 5) + e;
+                            if (k < y.D && mask_in(mk, c.s, p.n_curves, y.D, orig, k) == 0.0f)
+                                xm[q][i][e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
     // branch-free staging: threads beyond the image duplicate its last word (same value to the same address)
     auto load_step = [&](int q, int t, u32x4 (&pre)[NPT]) {
         if (FIRST) t = t < Tt[q] ? t : Tt[q] - 1;   // tile q may hold fewer steps than the pair runs
@@ -126,7 +179,7 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
-            xin[q * XS + f] = pre[i];
+            xin[q * XS + f] = (MASKED && FIRST) ? (pre[i] & xm[q][i]) : pre[i];
         }
     };
 
@@ -161,8 +214,9 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
                 if (p.n_curves < 0)
 #endif
                 {
-                reinterpret_cast<uint2*>(yo + 0 * 64)[c.hf] = uint2{r.ph[0] & vbits, r.ph[1] & vbits};
-                reinterpret_cast<uint2*>(yo + 1 * 64)[c.hf] = uint2{r.pl[0] & vbits, r.pl[1] & vbits};
+                const unsigned int v0 = MASKED ? vbits & ymask[qa][0] : vbits, v1 = MASKED ? vbits & ymask[qa][1] : vbits;
+                reinterpret_cast<uint2*>(yo + 0 * 64)[c.hf] = uint2{r.ph[0] & v0, r.ph[1] & v1};
+                reinterpret_cast<uint2*>(yo + 1 * 64)[c.hf] = uint2{r.pl[0] & v0, r.pl[1] & v1};
                 }
             }
             return;
@@ -308,6 +362,13 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
                     fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
                 }
             }
+            if (MASKED && masked) {
+                const int orig = (q == 0 || has1) ? info[(2 * pr + q) * 64 + 32 + c.cl] : -1;
+                if (orig >= 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) feat[u] = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, orig, fidx[u]), feat[u]);
+                }
+            }
             for (int cq = 0; cq < y.C; ++cq) {
                 float a = 0.0f;
 #pragma unroll
@@ -329,7 +390,7 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
   }
 }
 
-template <int H, int XB0, int DIRS>
+template <int H, int XB0, int DIRS, bool MASKED>
 __global__ void __launch_bounds__(H * 8, SNN_H2_WAVES) lstm_fwd_h2_kernel(const FwdParams p, const B3Offsets o)
 {
     constexpr int NT = H * 8, NW = H / 8, HB = H / 16;
@@ -384,11 +445,11 @@ __global__ void __launch_bounds__(H * 8, SNN_H2_WAVES) lstm_fwd_h2_kernel(const 
                 for (int d = 0; d < DIRS; ++d) {
                     const int ld = l * DIRS + d;
                     if (l == 0) {
-                        if (last) h2_phase<H, XB0, DIRS, true, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                        else h2_phase<H, XB0, DIRS, true, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        if (last) h2_phase<H, XB0, DIRS, true, true, MASKED>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else h2_phase<H, XB0, DIRS, true, false, MASKED>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
                     } else {
-                        if (last) h2_phase<H, XB1, DIRS, false, true>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
-                        else h2_phase<H, XB1, DIRS, false, false>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        if (last) h2_phase<H, XB1, DIRS, false, true, MASKED>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
+                        else h2_phase<H, XB1, DIRS, false, false, MASKED>(p, c, n_live, tile0, info, l, d, o.k_A[ld], o.k_bias[ld], o.k_head_w, xin, hb, part, logit, bl, ybase);
                     }
                 }
             }
@@ -419,12 +480,17 @@ __global__ void __launch_bounds__(H * 8, SNN_H2_WAVES) lstm_fwd_h2_kernel(const 
 
 // ---- registry hook used by snn_forward.hip -----------------------------------------------------------
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
-fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs)
+fwd_b3_kernel_t snn_h2_kernel(int H, int XB0, int dirs, bool masked)
 {
     if (H == 32 && dirs == 2) {
-        if (XB0 == 2) return lstm_fwd_h2_kernel<32, 2, 2>;   // D <= 26 (buckets 24, 26)
-        if (XB0 == 3) return lstm_fwd_h2_kernel<32, 3, 2>;   // D <= 48
-        if (XB0 == 5) return lstm_fwd_h2_kernel<32, 5, 2>;   // D <= 78
+        if (masked) {   // (the D <= 78 variant has no registers left for the staged input-mask words)
+            if (XB0 == 2) return lstm_fwd_h2_kernel<32, 2, 2, true>;
+            if (XB0 == 3) return lstm_fwd_h2_kernel<32, 3, 2, true>;
+            return nullptr;
+        }
+        if (XB0 == 2) return lstm_fwd_h2_kernel<32, 2, 2, false>;   // D <= 26 (buckets 24, 26)
+        if (XB0 == 3) return lstm_fwd_h2_kernel<32, 3, 2, false>;   // D <= 48
+        if (XB0 == 5) return lstm_fwd_h2_kernel<32, 5, 2, false>;   // D <= 78
     }
     return nullptr;
 }

@@ -86,8 +86,8 @@ class _HipRNN(nn.Module):
     def infer_cfg(self, masked=False):
         """Engine config of an inference launch: the module's cfg, in `inference_precision` when that mode has a
         kernel for this shape and the launch carries no masks."""
-        if masked or self.inference_precision == "f32" or isinstance(self, VariationalRNN):
-            return self.cfg      # (VariationalRNN keeps one fp32 weight image for masked and mean-field launches)
+        if masked or self.inference_precision == "f32":
+            return self.cfg      # (VariationalRNN overrides this: its f16x2 kernel takes masks)
         cfg = self.cfg.with_precision(self.inference_precision)
         return cfg if cfg.supported() else self.cfg
 
@@ -340,10 +340,46 @@ class VariationalRNN(_HipRNN):
     def _n_curves(self, x):
         return int(x.batch_sizes[0]) if isinstance(x, PackedSequence) else x.size(1)
 
+    def infer_cfg(self, masked=False):
+        """fp32 unless `inference_precision == "f16x2"` and that mode has a kernel for this launch (masked launches:
+        input width <= 48, i.e. up to 5 filters; see snn_forward_h2.hip)."""
+        if self.inference_precision != "f16x2":
+            return self.cfg
+        cfg = self.cfg.with_precision("f16x2")
+        if not cfg.supported() or (masked and self.input_size > 48):
+            return self.cfg
+        return cfg
+
+    def _infer_weights(self, masks):
+        """Kernel-layout weights of an inference launch.  The f16x2 kernel applies the dropout BITS exactly (ANDs on
+        the fp16 pieces) and expects the masks' 1/(1-p) factor inside the weights that multiply a masked operand
+        (include/snn_hip.h): W_ih of layer 0 (input mask), W_hh of the forward directions (W_hh row mask), W_ih of
+        the layers above (between-layer mask)."""
+        cfg = self.infer_cfg(masks is not None)
+        flat = self._flat("w")
+        if masks is not None and cfg.precision == "f16x2":
+            arrays = masks.mode == L.SNN_MASK_ARRAYS
+            on = [(masks.m_in is not None) if arrays else bool(masks.which & 1),
+                  (masks.m_whh is not None) if arrays else bool(masks.which & 2),
+                  (masks.m_mid is not None) if arrays else bool(masks.which & 4)]
+            scale = float(np.float32(1.0) / np.float32(1.0 - masks.dropout if not arrays else 1.0 - self.dropout))
+            flat = flat.clone()
+            H, dirs, off = self.hidden_size, _dirs(self.bidirectional), 0
+            for l in range(self.num_layers):
+                I = self.input_size if l == 0 else H * dirs
+                for d in range(dirs):
+                    if on[0] if l == 0 else on[2]:
+                        flat[off:off + 4 * H * I] *= scale
+                    off += 4 * H * I
+                    if d == 0 and on[1]:
+                        flat[off:off + 4 * H * H] *= scale
+                    off += 4 * H * H + 8 * H
+        return E.prepare_weights(cfg, flat)
+
     def mc_weights(self, n_samples, n_curves, device, mean_field_inference=False):
         """(kernel-layout weights, masks) for n_samples MC-dropout forwards over n_curves curves."""
-        wk = E.prepare_weights(self.cfg, self._flat("w"))
-        return wk, self._masks(n_samples, n_curves, device, mean_field_inference)
+        masks = self._masks(n_samples, n_curves, device, mean_field_inference)
+        return self._infer_weights(masks), masks
 
     def forward(self, x, mean_field_inference=False, masks=None):
         dev = x.data.device if isinstance(x, PackedSequence) else x.device
@@ -352,17 +388,15 @@ class VariationalRNN(_HipRNN):
         if self._use_train_path():
             logits, _ = self._train_forward(x, lambda plan: masks)
             return logits
-        wk = E.prepare_weights(self.cfg, self._flat("w"))
-        (logits, _), _ = self._launch(x, wk, 1, masks)
+        (logits, _), _ = self._launch(x, self._infer_weights(masks), 1, masks)
         return logits[0]
 
     def forward_mc(self, x, n_samples, mean_field_inference=False, masks=None):
         """All n_samples MC-dropout forwards in one launch -> probs (B, n_samples, C)."""
-        wk = E.prepare_weights(self.cfg, self._flat("w"))
         dev = x.data.device if isinstance(x, PackedSequence) else x.device
         if masks is None:
             masks = self._masks(n_samples, self._n_curves(x), dev, mean_field_inference)
-        (_, probs), _ = self._launch(x, wk, n_samples, masks, want_probs=True)
+        (_, probs), _ = self._launch(x, self._infer_weights(masks), n_samples, masks, want_probs=True)
         return probs.permute(1, 0, 2)
 
 

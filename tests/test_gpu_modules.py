@@ -49,11 +49,16 @@ def test_vanilla_module():
     assert preds.dtype == np.float32 and rel_err(preds, g["probs"]) < PROB_RTOL
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
 @pytest.mark.parametrize("tag,kw,D", [("mean", {}, 24), ("standard", dict(rnn_output_option="standard", nb_classes=4), 26)])
-def test_variational_module_seed_replay(tag, kw, D):
+def test_variational_module_seed_replay(tag, kw, D, prec):
+    """Host-drawn masks in the reference's order reproduce the reference's stochastic logits; in f16x2 the kernel
+    applies the mask bits on the fp16 pieces and the 1/(1-p) factors sit in the weights (same parity bar)."""
     g = load_golden(f"g2_variational_{tag}")
     rnn = _model("variational", g["sd"], D, **kw)
     rnn.draws = "host"
+    rnn.inference_precision = prec
+    assert rnn.infer_cfg(True).precision == prec
     with torch.no_grad():
         for s in range(g["logits"].shape[0]):
             torch.manual_seed(1000 + s)
@@ -105,14 +110,15 @@ def test_forward_mc_and_ragged_predict_match_sequential_forwards():
     assert np.array_equal(pr.cpu().numpy(), mc[perm])
 
 
-@pytest.mark.parametrize("model", ["bayesian", "variational"])
-def test_sampled_mode_statistics(model):
+@pytest.mark.parametrize("model,prec", [("bayesian", "f32"), ("variational", "f32"), ("variational", "f16x2")])
+def test_sampled_mode_statistics(model, prec):
     """Sampled (Philox) mode vs the reference's predictive mean/std (2000 reference draws, fixture g5).
     Tolerances: per-curve |mean - mean_ref| <= 4*sqrt(2)*std_ref/sqrt(S) for >= 99.9 % of curves
     (+1e-4 absolute floor), pooled mean bias < 1e-3, pooled predictive std within +-10 %."""
     from supernnova_amd.validation import validate_rnn as vr
     g = load_golden(f"g5_mcstats_{model}")
     rnn = _model(model, g["sd"], 24, dropout=float(g["dropout"]))
+    rnn.inference_precision = prec
     S = 2000
     torch.manual_seed(123)
     curves = [g["x"][: g["lengths"][b], b] for b in range(g["x"].shape[1])]
@@ -133,6 +139,11 @@ def test_sampled_mode_statistics(model):
         torch.manual_seed(5); b = vr.predict_mc(rnn, curves, 4).cpu().numpy()
         torch.manual_seed(6); c = vr.predict_mc(rnn, curves, 4).cpu().numpy()
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+    if prec != "f32":   # same seed, same Philox mask bits in both kernels: the precisions agree to the parity bar
+        rnn.inference_precision = "f32"
+        with torch.no_grad():
+            torch.manual_seed(5); a32 = vr.predict_mc(rnn, curves, 4).cpu().numpy()
+        assert rel_err(a, a32) < PROB_RTOL
 
 
 @pytest.mark.parametrize("fast", ["bf16x3", "f16x2"])
