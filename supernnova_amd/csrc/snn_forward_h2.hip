@@ -197,13 +197,15 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
     auto act_piece = [&](int qa, int ta, const f32x16& aM, const f32x16& aX, ActRegs& r, unsigned long long vmask,
                          unsigned int vbits, int piece) {
         // `pin`: an empty volatile asm on the piece's input keeps the piece behind the sched_barrier before it
-        auto pin = [](f2 v) { asm volatile("" : "+v"(v)); return v; };
-        // gate g of pair k: main + 2^-11 * cross
-        auto gate = [&](int g, int k) {
-            return fma_2(f2{aX[4 * g + 2 * k], aX[4 * g + 2 * k + 1]}, f2{SNN_H2_LO_INV, SNN_H2_LO_INV},
-                         f2{aM[4 * g + 2 * k], aM[4 * g + 2 * k + 1]});
-        };
-        const f2 one = f2{1.0f, 1.0f}, mtwo = f2{-2.0f, -2.0f};
+        auto pin = [](float v) { asm volatile("" : "+v"(v)); return v; };
+        // Scalar fp32 instructions on the two units of a pair, interleaved: beside MFMAs a packed fp32 instruction
+        // costs far more issue time than two scalar ones (MI355X_MICROARCH.md), and with two independent chains the
+        // consumer of a v_exp_f32 / v_rcp_f32 result is never the next instruction issued (no `s_nop` for the
+        // transcendental-use hazard).  Built with -fno-slp-vectorize so the compiler does not re-pack them.
+        // gate g of unit u: main + 2^-11 * cross
+        auto gate = [&](int g, int u) { return fmaf(aX[4 * g + u], SNN_H2_LO_INV, aM[4 * g + u]); };
+        auto ex = [](float v) { return __builtin_amdgcn_exp2f(v); };
+        auto rc = [](float v) { return __builtin_amdgcn_rcpf(v); };
         if (piece == 16) {
             u32x4* hn = hb + qa * HS;
             reinterpret_cast<uint2*>(hn + (hblk * 2 + 0) * 64 + hlane)[c.hf] = uint2{r.ph[0], r.ph[1]};
@@ -221,32 +223,48 @@ __device__ __forceinline__ void h2_phase(const FwdParams& p, const H2Ctx& c, int
             }
             return;
         }
-        const int k = piece >> 3, st = piece & 7;
-        if (st == 0) r.di[k] = one + exp2_2(pin(gate(0, k)));                    // 1 + e^-i
-        else if (st == 1) r.dg[k] = one + exp2_2(pin(gate(2, k)));               // 1 + e^2g
-        else if (st == 2) r.df[k] = one + exp2_2(pin(gate(1, k)));               // 1 + e^-f
-        else if (st == 3) {
-            r.ig[k] = rcp_2(pin(r.di[k]));
-            r.gg[k] = fma_2(mtwo, rcp_2(r.dg[k]), one);                          // tanh(g)
+        const int k = piece >> 3, st = piece & 7, ua = 2 * k, ub = 2 * k + 1;
+        if (st == 0) {                                                            // 1 + e^-i
+            const float a = ex(pin(gate(0, ua))), b = ex(pin(gate(0, ub)));
+            r.di[k] = f2{1.0f + a, 1.0f + b};
+        } else if (st == 1) {                                                     // 1 + e^2g
+            const float a = ex(pin(gate(2, ua))), b = ex(pin(gate(2, ub)));
+            r.dg[k] = f2{1.0f + a, 1.0f + b};
+        } else if (st == 2) {                                                     // 1 + e^-f
+            const float a = ex(pin(gate(1, ua))), b = ex(pin(gate(1, ub)));
+            r.df[k] = f2{1.0f + a, 1.0f + b};
+        } else if (st == 3) {
+            const float ia = rc(pin(r.di[k].x)), ib = rc(pin(r.di[k].y));
+            const float ga = rc(r.dg[k].x), gb = rc(r.dg[k].y);
+            r.ig[k] = f2{ia, ib};
+            r.gg[k] = f2{fmaf(-2.0f, ga, 1.0f), fmaf(-2.0f, gb, 1.0f)};            // tanh(g)
         } else if (st == 4) {
-            const f2 cn = fma_2(rcp_2(pin(r.df[k])), cst[qa][k], r.ig[k] * r.gg[k]);
-            r.dc[k] = cn * f2{2.88539008177792681f, 2.88539008177792681f};
-            cst[qa][k] = f2{lane_select(vmask, cn.x, cst[qa][k].x), lane_select(vmask, cn.y, cst[qa][k].y)};
+            const float fa = rc(pin(r.df[k].x)), fb = rc(pin(r.df[k].y));
+            const float pa = r.ig[k].x * r.gg[k].x, pb = r.ig[k].y * r.gg[k].y;
+            const float ca = fmaf(fa, cst[qa][k].x, pa), cb = fmaf(fb, cst[qa][k].y, pb);
+            r.dc[k] = f2{ca * 2.88539008177792681f, cb * 2.88539008177792681f};
+            cst[qa][k] = f2{lane_select(vmask, ca, cst[qa][k].x), lane_select(vmask, cb, cst[qa][k].y)};
         } else if (st == 5) {
-            r.dc[k] = one + exp2_2(pin(r.dc[k]));                                // 1 + e^2c
-            r.dq[k] = one + exp2_2(gate(3, k));                                  // 1 + e^-o
+            const float ca = ex(pin(r.dc[k].x)), cb = ex(pin(r.dc[k].y));            // e^2c
+            const float oa = ex(gate(3, ua)), ob = ex(gate(3, ub));                  // e^-o
+            r.dc[k] = f2{1.0f + ca, 1.0f + cb};
+            r.dq[k] = f2{1.0f + oa, 1.0f + ob};
         } else if (st == 6) {
-            const f2 hv = rcp_2(pin(r.dq[k])) * fma_2(mtwo, rcp_2(r.dc[k]), one);   // sigmoid(o) tanh(c)
-            hst[qa][k] = f2{lane_select(vmask, hv.x, hst[qa][k].x), lane_select(vmask, hv.y, hst[qa][k].y)};
-            if (LAST) hsum[qa][k] += f2{lane_select(vmask, hv.x, 0.0f), lane_select(vmask, hv.y, 0.0f)};
+            const float oa = rc(pin(r.dq[k].x)), ob = rc(pin(r.dq[k].y));
+            const float ta_ = rc(r.dc[k].x), tb_ = rc(r.dc[k].y);
+            const float ha = oa * fmaf(-2.0f, ta_, 1.0f), hb_ = ob * fmaf(-2.0f, tb_, 1.0f);   // sigmoid(o) tanh(c)
+            hst[qa][k] = f2{lane_select(vmask, ha, hst[qa][k].x), lane_select(vmask, hb_, hst[qa][k].y)};
+            if (LAST) {
+                hsum[qa][k].x += lane_select(vmask, ha, 0.0f);
+                hsum[qa][k].y += lane_select(vmask, hb_, 0.0f);
+            }
         } else {   // split2 of the pair
-            const f2 hv = pin(hst[qa][k]);
-            const unsigned int hi = cvt_pk_f16(hv.x, hv.y);
-            const f2 hf = f2{(float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu)),
-                             (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16))};
-            const f2 rs = (hv - hf) * f2{SNN_H2_LO_SCALE, SNN_H2_LO_SCALE};
+            const float ha = pin(hst[qa][k].x), hb_ = pin(hst[qa][k].y);
+            const unsigned int hi = cvt_pk_f16(ha, hb_);
+            const float fa = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu));
+            const float fb = (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16));
             r.ph[k] = hi;
-            r.pl[k] = cvt_pk_f16(rs.x, rs.y);
+            r.pl[k] = cvt_pk_f16((ha - fa) * SNN_H2_LO_SCALE, (hb_ - fb) * SNN_H2_LO_SCALE);
         }
     };
     // One pipeline phase: the MFMA chains of tile qc (into mc / xc), with the cell update of tile qa (from ma / xa, step
