@@ -145,3 +145,60 @@ def get_predictions_for_speed_benchmark(settings, rnn, list_data):
         probs = predict_mc(rnn, [d[0] for d in list_data], S).cpu().numpy()
     total = time() - start
     return len(list_data) / total, probs
+
+
+def flatten_to_dataframe(pred_dict):
+    """(N, S, C) arrays -> one row per (curve, sample): columns `<key>_class<i>`, `target`, `SNID`
+    (validate_rnn.py:147-160)."""
+    import pandas as pd
+    n, s, _ = pred_dict["all"].shape
+    cols = {}
+    for key, value in pred_dict.items():
+        v = value.reshape(n * s, -1)
+        if v.shape[1] == 1:
+            cols[key] = v.ravel()
+        else:
+            for i in range(v.shape[1]):
+                cols[f"{key}_class{i}"] = v[:, i]
+    return pd.DataFrame.from_dict(cols)
+
+
+def get_aggregated_dataframe(pred_df):
+    """Per-SNID median and std (ddof = 1) of every column over the MC samples (validate_rnn.py:163-172)."""
+    import pandas as pd
+    g = pred_df.groupby("SNID")
+    med, std = g.median(), g.std()
+    med.columns = [f"{c}_median" for c in med.columns]
+    std.columns = [f"{c}_std" for c in std.columns]
+    agg = pd.merge(med, std, on="SNID")
+    agg["SNID"] = agg.index
+    agg["target"] = agg["target_median"]
+    return agg
+
+
+def get_predictions(settings, model_file=None, list_data=None, peak_mjds=None, times=None, rnn=None):
+    """The RNN branch of validate_rnn.get_predictions (:229-442): load the state dict, run the MC and the
+    mean-field passes, write `PRED_<model>.pickle` (one row per curve and sample) and, for the variational and
+    Bayesian models, `PRED_<model>_aggregated.pickle`; returns the list of prediction files.
+    `list_data` is the test list tu.load_HDF5(settings, test=True) would return (HDF5 is out of scope here);
+    PEAKMJD offsets are filled when `peak_mjds` / `times` (per-curve arrays of observation times) are given.
+    The state dict is read with weights_only=True."""
+    import os
+    if list_data is None:
+        raise ValueError("supernnova_amd.validation.validate_rnn.get_predictions takes the test list of "
+                         "tu.load_HDF5 as `list_data`: the HDF5 reader is not part of this package")
+    if rnn is None:
+        rnn = tu.get_model(settings, list_data[0][0].shape[1])
+        if model_file is None:
+            model_file = os.path.join(str(settings.rnn_dir), f"{settings.pytorch_model_name}.pt")
+        rnn.load_state_dict(torch.load(model_file, map_location="cpu", weights_only=True))
+        rnn.to(getattr(settings, "device", "cuda"))
+    rnn.eval()
+    dump_dir = getattr(settings, "dump_dir", None) or os.path.dirname(os.path.abspath(model_file or str(settings.rnn_dir) + "/x"))
+    d_pred, d_pred_mfe = get_predictions_mc(settings, rnn, list_data, peak_mjds, times)
+    df = flatten_to_dataframe(d_pred)
+    pred_file = os.path.join(dump_dir, f"PRED_{settings.pytorch_model_name}.pickle")
+    df.to_pickle(pred_file, protocol=4)
+    if settings.model in ("variational", "bayesian"):
+        get_aggregated_dataframe(df).to_pickle(pred_file.replace(".pickle", "_aggregated.pickle"), protocol=4)
+    return [pred_file]

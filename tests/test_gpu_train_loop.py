@@ -79,3 +79,33 @@ def test_lr_range_test_and_one_cycle(tmp_path):
     st.cyclic = True
     train_rnn.train(st, train, val)
     assert os.path.isfile(tmp_path / "training_log.json")
+
+
+@pytest.mark.parametrize("model", ["vanilla", "bayesian"])
+def test_get_predictions_writes_the_reference_pickles(tmp_path, model):
+    """Train briefly, then validate_rnn.get_predictions: PRED_<model>.pickle with one row per (curve, sample) and the
+    reference's columns; the aggregated pickle for the Bayesian model; accuracy of the per-SNID median prediction."""
+    import pandas as pd
+    from supernnova_amd.training import train_rnn
+    from supernnova_amd.validation import validate_rnn as vr
+    np.random.seed(3)
+    torch.manual_seed(3)
+    train, val, test = _dataset(512, 5), _dataset(128, 6), _dataset(96, 7)
+    st = _settings(tmp_path, model, num_inference_samples=7, device="cuda", dump_dir=str(tmp_path))
+    st.nb_epoch = 16 if model == "bayesian" else 4
+    train_rnn.train(st, train, val)
+    np.random.seed(4)
+    files = vr.get_predictions(st, list_data=test)
+    assert files == [str(tmp_path / f"PRED_{st.pytorch_model_name}.pickle")]
+    df = pd.read_pickle(files[0])
+    S = 1 if model == "vanilla" else 7
+    assert len(df) == len(test) * S
+    assert {"all_class0", "all_class1", "all_reverse_class0", "all_shuffle_class1", "target", "SNID"} <= set(df.columns)
+    np.testing.assert_allclose(df["all_class0"] + df["all_class1"], 1.0, atol=1e-6)
+    med = df.groupby("SNID")[["all_class0", "all_class1", "target"]].median()
+    assert (med[["all_class0", "all_class1"]].values.argmax(1) == med["target"].values).mean() > 0.9
+    agg_file = tmp_path / f"PRED_{st.pytorch_model_name}_aggregated.pickle"
+    assert agg_file.exists() == (model == "bayesian")
+    if model == "bayesian":
+        agg = pd.read_pickle(agg_file)
+        assert len(agg) == len(test) and (agg["all_class1_std"] > 0).all()

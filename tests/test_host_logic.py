@@ -195,3 +195,27 @@ def test_plateau_loss_string_schedule_and_training_log(tmp_path):
 
     with pytest.raises(ValueError):
         train_rnn.train(settings())          # no data lists: the HDF5 reader is not part of the package
+
+
+def test_prediction_dataframes_match_the_reference_layout():
+    """flatten_to_dataframe / get_aggregated_dataframe (validate_rnn.py:147-172): column names, row order, and the
+    device-side aggregate() against pandas' per-SNID median / std (ddof = 1)."""
+    from supernnova_amd.validation import validate_rnn as vr
+    g = np.random.default_rng(0)
+    N, S, C = 7, 6, 2
+    d = vr.construct_predict_dict(N, S, C)
+    p = g.random((N, S, 1)).astype(np.float32)
+    d["all"][:] = np.concatenate([p, 1 - p], -1)
+    d["target"][:] = g.integers(0, 2, N)[:, None]
+    d["SNID"][:] = np.array([str(100 + i) for i in range(N)])[:, None]
+    df = vr.flatten_to_dataframe(d)
+    assert len(df) == N * S and {"all_class0", "all_class1", "target", "SNID", "PEAKMJD-2_class0",
+                                 "all_sin_class1"} <= set(df.columns)
+    assert np.array_equal(df["all_class1"].values.reshape(N, S), d["all"][..., 1])
+    agg = vr.get_aggregated_dataframe(df)
+    assert list(agg["SNID"]) == sorted(str(100 + i) for i in range(N)) and "all_class0_std" in agg.columns
+    med, std = vr.aggregate(torch.from_numpy(d["all"]))
+    order = np.argsort([str(100 + i) for i in range(N)])
+    np.testing.assert_allclose(agg["all_class0_median"].values, med.numpy()[order, 0], rtol=1e-6)
+    np.testing.assert_allclose(agg["all_class0_std"].values, std.numpy()[order, 0], rtol=1e-5)
+    assert np.array_equal(agg["target"].values, d["target"][order, 0])
