@@ -136,11 +136,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from supernnova_amd import engine as E
 
@@ -219,11 +226,38 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    selfcheck = None
     if not os.environ.get("SNN_BENCH_NOCHECK"):      # timing-ablation builds produce garbage on purpose
         assert bool(torch.isfinite(probs).all()) and bool(torch.isfinite(kl).all())
+        # Size-independent property at the full bench size: a random subset of the curves, run again as a launch of
+        # its own with the same weight draws, must reproduce its rows of the big launch bit for bit (results do not
+        # depend on tiling, work-queue order or the number of curves in flight).
+        gsub = torch.Generator(device="cpu")
+        gsub.manual_seed(7 + rank)
+        sub = torch.randperm(N, generator=gsub)[:min(N, 3000)].sort().values
+        sub_d = sub.to(dev)
+        splan = E.Plan(cfg, lengths_host[sub.numpy()], dev)
+        sxp = E.pack_x(cfg, splan, x[:, sub_d].contiguous())
+        i_last = args.warmup + args.steps - 1
+        if var:
+            swk, smasks = w_var, E.Masks(mode=2, which=0xF, dropout=0.05, seed=1234, offset=i_last * S)
+            # (per-curve Philox masks are keyed by the curve index, which changes in the subset: compare shapes only)
+        else:
+            swk, _ = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i_last * S)
+            smasks = None
+        _, sprobs = E.lstm_forward(cfg, splan, sxp, swk, S, masks=smasks, want_logits=False, want_probs=True,
+                                   sample_major=False)
+        torch.cuda.synchronize()
+        if var:
+            same = sprobs.shape == probs[sub_d].shape and bool(torch.isfinite(sprobs).all())
+            selfcheck = f"{len(sub)} curves re-run in a separate launch: finite (masks are keyed by curve index)"
+        else:
+            same = bool(torch.equal(sprobs, probs[sub_d]))
+            selfcheck = f"{len(sub)} random curves re-run in a separate launch with the same draws: bit-identical"
+        assert same, "subset launch does not reproduce the rows of the full-size launch"
 
     if rank == 0:
         value = world * N * args.steps / dt
@@ -254,7 +288,7 @@ def main():
                        "light curves/s classified, BayesianRNN 50 MC samples"),
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "weak", "vs_baseline": None, "selfcheck": selfcheck,
             "dtype": (f"f32 (each product = {npr} {'bf16' if npr == 6 else 'fp16'} piece products, fp32 accumulate)"
                       if b3 else "f32"), "data": "synthetic",
             "config": {"workload": (f"BayesianRNN (BBB) LSTM 128x2 bidirectional, mean pooling, D=78 (6 filters + redshift), "
