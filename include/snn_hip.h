@@ -175,6 +175,14 @@ int snn_pack_x(const snn_cfg *cfg, const float *x, int64_t stride_t, int64_t str
 int snn_prepare_weights(const snn_cfg *cfg, const float *flat, float *wk, void *stream);
 
 /*
+ * The same for n_samples canonical weight sets at once (set s starts at flat + s * sample_stride; wk receives
+ * n_samples x PK floats): the per-sample models SwagModel.sample draws one deepcopy at a time in
+ * utils/swag_utils.py:268-335, called per MC sample by validate_rnn.get_batch_predictions_SWAG (:89-112).
+ */
+int snn_prepare_weights_multi(const snn_cfg *cfg, const float *flat, int64_t sample_stride, int32_t n_samples,
+                              float *wk, void *stream);
+
+/*
  * Bayes-by-Backprop draw of S weight sets + their KL; replaces
  * BayesLSTM.forward's sampling loop and BayesLinear.forward
  * (training/bayesian_rnn.py:472-528, 595-616) and compute_KL (:794-815):

@@ -59,6 +59,7 @@ SIGNATURES = {
     "snn_pack_x": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P,
                                   ctypes.c_int32, ctypes.c_int64, _P, _P]),
     "snn_prepare_weights": (ctypes.c_int, [_CFG, _P, _P, _P]),
+    "snn_prepare_weights_multi": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int32, _P, _P]),
     "snn_bbb_sample": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                       ctypes.c_int32, ctypes.POINTER(SnnPrior), _P, _P, _P, _P]),
     "snn_lstm_forward_workspace_bytes": (ctypes.c_int64, [_CFG, ctypes.c_int32]),

@@ -109,10 +109,12 @@ __global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const floa
                                                         const float* __restrict__ rho,
                                                         const float* __restrict__ eps, int mode,
                                                         uint64_t seed, uint64_t offset, snn_prior prior,
-                                                        float* __restrict__ wk, float* __restrict__ kl_terms)
+                                                        float* __restrict__ wk, float* __restrict__ kl_terms,
+                                                        int64_t mu_stride)
 {
     __shared__ double sh[4];
     const int tau = blockIdx.x, s = blockIdx.y;
+    mu += (int64_t)s * mu_stride;   // snn_prepare_weights_multi: one canonical weight set per sample
     const TensorGeom g = tensor_geom(y, tau);
     const int64_t Ps = y.P - y.C;
     float* dst = wk + (int64_t)s * y.PK;
@@ -354,12 +356,12 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
 
 static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, const float* eps, int mode,
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
-                         float* kl_terms, hipStream_t st)
+                         float* kl_terms, hipStream_t st, int64_t mu_stride = 0)
 {
     if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0)  // padding words exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
     hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
-                       offset, prior, wk, kl ? kl_terms : nullptr);
+                       offset, prior, wk, kl ? kl_terms : nullptr, mu_stride);
     HIP_CHECK(hipGetLastError());
     if (kl) {
         hipLaunchKernelGGL(kl_sum_kernel, dim3((S + 63) / 64), dim3(64), 0, st, y.n_tensors, S, kl_terms, kl);
@@ -376,6 +378,22 @@ extern "C" int snn_prepare_weights(const snn_cfg* cfg, const float* flat, float*
     if (!flat || !wk) { snn_set_error("snn_prepare_weights: null pointer"); return SNN_ERR_ARG; }
     snn_prior pr = {0.5f, 1.f, 1.f, 1.f, 1.f};
     return launch_sample(y, flat, nullptr, nullptr, 1, 0, 0, 1, pr, wk, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snn_prepare_weights_multi(const snn_cfg* cfg, const float* flat, int64_t sample_stride, int32_t n_samples,
+                                         float* wk, void* stream)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (!flat || !wk || n_samples < 1 || n_samples > 65535 || sample_stride < y.P) {
+        snn_set_error("snn_prepare_weights_multi: null pointer, n_samples out of [1, 65535] or sample_stride < %lld",
+                      (long long)y.P);
+        return SNN_ERR_ARG;
+    }
+    snn_prior pr = {0.5f, 1.f, 1.f, 1.f, 1.f};
+    return launch_sample(y, flat, nullptr, nullptr, 1, 0, 0, n_samples, pr, wk, nullptr, nullptr, (hipStream_t)stream,
+                         sample_stride);
 }
 
 extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* rho, const float* eps, int32_t mode,

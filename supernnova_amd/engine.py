@@ -168,6 +168,17 @@ def prepare_weights(cfg, flat):
     return wk
 
 
+def prepare_weights_multi(cfg, flats):
+    """(S, P) canonical weight sets -> (S, PK) kernel layout, one launch."""
+    _require_cuda(flats, "flats")
+    if flats.dim() != 2 or flats.size(1) != cfg.P or not flats.is_contiguous() or flats.dtype != torch.float32:
+        raise L.SnnError(f"flats must be a contiguous fp32 (S, {cfg.P}) tensor, got {tuple(flats.shape)} {flats.dtype}")
+    wk = torch.empty((flats.size(0), cfg.PK), dtype=torch.float32, device=flats.device)
+    L.check(L.load().snn_prepare_weights_multi(ctypes.byref(cfg.c), _ptr(flats), cfg.P, flats.size(0), _ptr(wk), _stream()),
+            "snn_prepare_weights_multi")
+    return wk
+
+
 @dataclass(frozen=True)
 class Prior:
     """training/bayesian_rnn.py:753-763 for the LSTM and the output layer."""

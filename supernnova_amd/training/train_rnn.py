@@ -3,10 +3,11 @@
   train_cyclic        :98-222   1-cycle policy
   save_normalizations :225-242  data_norm.json
   train / train_      :245-372  decay-on-plateau policy, best-validation-loss checkpoint, training_log.json
+  train_swag          :375-516  SWAG statistics from swag_start_epoch on
 The loops are host glue; every step runs tu.train_step (forward tape, BPTT, BBB backward, fused Adam on the GPU).
 The reference reads its data with tu.load_HDF5(settings); HDF5 is out of scope here (h5py absent), so the
 loops take the two lists load_HDF5 would return -- `(X_normed[L, D] float32, target, ...)` tuples -- as arguments.
-SWAG (`train_swag*`) is out of scope.  Loss plots are not drawn."""
+`train_swag_finetune` is out of scope.  Loss plots are not drawn."""
 import json
 import os
 from time import time
@@ -165,10 +166,41 @@ def train_(settings, list_data_train=None, list_data_val=None):
     return rnn
 
 
+def train_swag(settings, list_data_train=None, list_data_val=None):
+    """SWAG training (train_rnn.py:375-516): the plain loop at a constant learning rate; from
+    `settings.swag_start_epoch` on, the parameters of every epoch enter the SwagModel statistics, and once three
+    models are averaged SWAG draws are evaluated and the SwagModel is saved.  The reference pickles the whole module
+    into `<name>_swag.pt`; here the file holds its state dict (same buffer names), loadable with weights_only=True.
+    Returns (rnn, swag_rnn)."""
+    from ..utils.swag_utils import SwagModel
+    list_data_train, list_data_val = _data(settings, list_data_train, list_data_val)
+    save_normalizations(settings)
+    rnn, criterion, optimizer = _setup(settings, list_data_train[0][0].shape[1])
+    swag_rnn = SwagModel(rnn)
+    d_train, d_val = _monitors(settings)
+    best_loss, t_start = float("inf"), time()
+    for epoch in range(settings.nb_epoch):
+        _run_epoch(settings, rnn, criterion, optimizer, list_data_train)
+        if (epoch + 1) % settings.monitor_interval == 0:
+            _, _, best_loss = _monitor(settings, rnn, list_data_train, list_data_val, d_train, d_val, epoch, best_loss)
+        if epoch >= settings.swag_start_epoch:
+            swag_rnn.update_parameters(rnn)
+            if epoch >= settings.swag_start_epoch + 2:      # K > 1 deviations: the covariance draw is defined
+                swag_rnn.last_metrics = tu.get_evaluation_metrics(settings, list_data_train, swag_rnn,
+                                                                  sample_size=len(list_data_val), swag_sampling=True)
+                torch.save(swag_rnn.state_dict(),
+                           os.path.join(str(settings.rnn_dir), f"{settings.pytorch_model_name}_swag.pt"))
+    tu.save_training_results(settings, d_val, time() - t_start)
+    return rnn, swag_rnn
+
+
 def train(settings, list_data_train=None, list_data_val=None):
-    """Entry point of `snn train_rnn` (train_rnn.py:245-256); SWAG variants are out of scope."""
-    if getattr(settings, "swag", False) or getattr(settings, "swag_pretrained_path", None):
-        raise ValueError("SWAG training is not part of supernnova_amd")
+    """Entry point of `snn train_rnn` (train_rnn.py:245-256 and cli/run.py:94-102); fine-tuning from a pre-trained
+    SWAG pickle (`train_swag_finetune`) is out of scope."""
+    if getattr(settings, "swag_pretrained_path", None):
+        raise ValueError("SWAG fine-tuning from a pickled model is not part of supernnova_amd")
+    if getattr(settings, "swag", False):
+        return train_swag(settings, list_data_train, list_data_val)
     if getattr(settings, "cyclic", False):
         return train_cyclic(settings, list_data_train, list_data_val)
     return train_(settings, list_data_train, list_data_val)

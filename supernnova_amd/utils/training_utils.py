@@ -22,10 +22,13 @@ _MODELS = {"vanilla": VanillaRNN, "variational": VariationalRNN, "bayesian": Bay
 def get_model(settings, input_size):
     """Create the RNN model `settings.model` names (training_utils.py:320-351)."""
     try:
-        cls = _MODELS[settings.model]
+        cls = VanillaRNN if settings.model == "swag" else _MODELS[settings.model]
     except KeyError:
-        raise ValueError(f"supernnova_amd implements models {sorted(_MODELS)}, got {settings.model!r}") from None
+        raise ValueError(f"supernnova_amd implements models {sorted(_MODELS) + ['swag']}, got {settings.model!r}") from None
     rnn = cls(input_size, settings)
+    if settings.model == "swag":          # SWAG statistics around a VanillaRNN (training_utils.py:337-345)
+        from .swag_utils import SwagModel
+        rnn = SwagModel(rnn)
     if not getattr(settings, "no_dump", True):
         print(rnn)
     return rnn
@@ -139,11 +142,19 @@ def eval_step(rnn, packed_tensor):
     return rnn(packed_tensor)
 
 
-def get_evaluation_metrics(settings, list_data, model, sample_size=None):
+def eval_step_swag(model, scale, cov, packed_tensor):
+    """One SWAG draw evaluated on a batch (training_utils.py:547-577): the draw goes through the per-sample-weights
+    kernel (SwagModel.forward_mc with one sample) instead of a deep-copied module; returns log-probabilities' logits
+    equivalent for the softmax that follows -- log of the class probabilities."""
+    model.eval()
+    return torch.log(model.forward_mc(packed_tensor, 1, scale=scale, cov=cov)[:, 0])
+
+
+def get_evaluation_metrics(settings, list_data, model, sample_size=None, swag_sampling=False):
     """AUC / accuracy / log-loss (/ mean KL) of `model` over `list_data`, batch by batch in eval mode -- one
-    stochastic forward per batch for the variational and Bayesian models, as the reference
-    (training_utils.py:609-707; its SWAG branch is out of scope).  Consumes numpy's global RNG for the
-    batch subsample exactly where the reference does."""
+    stochastic forward per batch for the variational and Bayesian models (and one SWAG draw per batch with
+    `swag_sampling`), as the reference (training_utils.py:609-707).  Consumes numpy's global RNG for the batch
+    subsample exactly where the reference does."""
     from sklearn import metrics
     n = len(list_data)
     batches = np.array_split(np.arange(n), n // min(n // 2, settings.batch_size))
@@ -159,7 +170,10 @@ def get_evaluation_metrics(settings, list_data, model, sample_size=None):
         finally:
             settings.random_length = keep
         with torch.no_grad():
-            out = eval_step(model, packed)
+            if swag_sampling:
+                out = eval_step_swag(model, settings.swag_scale, not getattr(settings, "swag_no_lr_cov", False), packed)
+            else:
+                out = eval_step(model, packed)
         if isinstance(model, BayesianRNN):
             kls.append(float(model.kl.detach()))
         preds.append(torch.softmax(out, dim=1).cpu().numpy()[rev])

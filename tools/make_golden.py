@@ -577,11 +577,56 @@ def g7_onthefly():
     save("g7_onthefly", **out)
 
 
+# ---------------------------------------------------------------- G8 SWAG
+def g8_swag():
+    """utils/swag_utils.py SwagModel around a VanillaRNN: 6 parameter snapshots (a random walk standing in for SGD
+    iterates) through update_parameters, then sample(scale, cov) with a fixed seed, 3 samples each with and without
+    the low-rank covariance term; logits of every sampled model and of the SWA mean.  The draws are captured by
+    re-seeding and repeating the reference's calls (randn_like(var) then normal_() of K) -- verified below."""
+    spec = importlib.util.spec_from_file_location("ref_swag_utils", "/root/reference/python/supernnova/utils/swag_utils.py")
+    swag_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(swag_utils)
+    torch.manual_seed(21)
+    st, D = settings(), 24
+    m = build(vanilla_rnn.VanillaRNN, D, st)
+    m.eval()
+    swag = swag_utils.SwagModel(m)
+    snaps = []
+    g = torch.Generator().manual_seed(5)
+    for it in range(6):
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+        snaps.append(flat_vanilla(sd_np(m), 2, 2))
+        swag.update_parameters(m)
+    x, lengths = make_batch(8, 22, 19, D)
+    packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in swag.state_dict().items()}
+    out = dict(sd=sd, snapshots=np.stack(snaps), x=x, lengths=lengths, scale=0.5)
+    with torch.no_grad():
+        out["logits_swa"] = swag(packed).numpy()
+    for cov in (True, False):
+        logits, flats = [], []
+        for s in range(3):
+            torch.manual_seed(3000 + s)
+            sm = swag.sample(0.5, cov)
+            sm.eval()
+            with torch.no_grad():
+                logits.append(sm(packed).numpy())
+            flats.append(flat_vanilla(sd_np(sm), 2, 2))
+        tag = "cov" if cov else "diag"
+        out[f"logits_{tag}"] = np.stack(logits)
+        out[f"flat_{tag}"] = np.stack(flats)
+        o = oracle.forward(ocfg(st, D), x, lengths, flats[0])
+        check(f"swag {tag} sample 0 vs oracle", o["logits"], logits[0])
+    save("g8_swag", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7", "g8"]
     if "g0" in which:
         g0_init()
     if "g1" in which:
@@ -596,3 +641,5 @@ if __name__ == "__main__":
         g5_mc_stats()
     if "g7" in which:
         g7_onthefly()
+    if "g8" in which:
+        g8_swag()
