@@ -338,3 +338,55 @@ def test_split_precision_results_do_not_depend_on_tiling(prec, D, C, pool, L, N,
         assert np.array_equal(lo1, lo[:, a:a + 32]) and np.array_equal(pr1, pr[:, a:a + 32])
     o = oracle.forward(ocfg, x, lengths, w)
     _check(lo[0], pr[0], o["logits"], o["probs"])
+
+
+def _fold_keep_scale(cfg, w, p):
+    """What SNN_PREC_F16X2 asks of the caller of a masked launch (include/snn_hip.h): 1/(1-p) inside W_ih of every
+    layer and W_hh of the forward directions."""
+    w = w.copy()
+    s, H, off = np.float32(1) / np.float32(1 - p), cfg.hidden_size, 0
+    for l in range(cfg.num_layers):
+        I = cfg.input_size if l == 0 else H * cfg.dirs
+        for d in range(cfg.dirs):
+            w[off:off + 4 * H * I] *= s
+            off += 4 * H * I
+            if d == 0:
+                w[off:off + 4 * H * H] *= s
+            off += 4 * H * H + 8 * H
+    return w
+
+
+@pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (42, 5, "standard", 2, 97, 17),
+                                            (26, 3, "mean", 1, 33, 9), (48, 2, "standard", 3, 131, 23),
+                                            (24, 2, "mean", 2, 1, 1)])
+def test_f16x2_with_variational_masks_vs_oracle(D, C, pool, L, N, T):
+    """Masked f16x2 launches (host-drawn mask arrays): mask bits applied on the fp16 pieces, keep-scale folded into
+    the weights -- against the C oracle's masked forward at the fp32 parity bar; odd tile counts, a dead partner
+    tile, 1..3 layers, both poolings, both instantiated input widths (XB0 = 2, 3).  Wider inputs are refused."""
+    E = _eng()
+    H, S, p = 32, 3, 0.1
+    cfg32 = E.Config(D, H, L, True, C, pool)
+    cfg = cfg32.with_precision("f16x2")
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    g = np.random.default_rng(51)
+    w = _random_model(cfg, 52, 0.15)
+    x, lengths = make_curves(53, N, T, D, min_len=1)
+    bern = lambda *s: (g.random(s) < 1 - p).astype(np.float32) / np.float32(1 - p)
+    m_in, m_whh, m_out = bern(S, N, D), bern(S, L, 4 * H), bern(S, N, cfg.F)
+    m_mid = bern(S, L - 1, 1, N, 2 * H) if L > 1 else None
+    masks = E.Masks(mode=1, m_in=_t(m_in), m_whh=_t(m_whh), m_mid=_t(m_mid) if L > 1 else None, m_out=_t(m_out), mid_T=1)
+    lo, pr = _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(_fold_keep_scale(cfg, w, p))), S, masks)
+    for s in range(S):
+        o = oracle.forward(ocfg, x, lengths, w, m_in[s], m_whh[s], m_mid[s] if L > 1 else None, m_out[s])
+        _check(lo[s], pr[s], o["logits"], o["probs"])
+
+
+def test_f16x2_masks_refused_for_wide_inputs():
+    E = _eng()
+    from supernnova_amd import _lib
+    cfg = E.Config(78, 32, 2, True, 2, "mean").with_precision("f16x2")
+    x, lengths = make_curves(54, 40, 8, 78, min_len=1)
+    w = _random_model(cfg, 55, 0.1)
+    masks = E.Masks(mode=2, which=0xF, dropout=0.1, seed=3)
+    with pytest.raises(_lib.SnnError):
+        _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(w)), 2, masks)
