@@ -168,6 +168,22 @@ int snn_pack_x(const snn_cfg *cfg, const float *x, int64_t stride_t, int64_t str
                const int64_t *tile_off, int32_t n_tiles, int64_t xp_floats, float *xp, void *stream);
 
 /*
+ * Host-only: the row-building half of the on-the-fly (broker) featuriser (validation/validate_onthefly.py:65-120 ->
+ * utils/data_utils.compute_delta_time :364-390, data/make_dataset.pivot_dataframe_single_from_df :800-938).
+ * snn_featurize_plan: observations (curve index, MJD) -> `order` (sorted by curve, then MJD, stable), and for the j-th
+ * observation in that order its output row `row_of[j]` and the first time of its 8-hour group `row_mjd_of[j]`
+ * (a new group opens at the first observation of a curve, at delta_time == 0, or more than min_dt after the running
+ * group's first time); rows_per_curve[n_curves]; returns the number of rows (< 0: error).
+ * snn_featurize_fill: per (row, filter) flux and error of the observation with the lowest error (earliest on
+ * ties); filt < 0 fills nothing; flux_out / err_out / present_out must arrive zeroed.
+ */
+int64_t snn_featurize_plan(int64_t n, int64_t n_curves, const int64_t *curve, const double *mjd, double min_dt,
+                           int64_t *order, int64_t *row_of, double *row_mjd_of, int64_t *rows_per_curve);
+int snn_featurize_fill(int64_t n, int64_t n_rows, int32_t F, const int64_t *order, const int64_t *row_of,
+                       const double *row_mjd_of, const double *flux, const double *err, const int64_t *filt,
+                       double *flux_out, double *err_out, uint8_t *present_out, double *row_mjd);
+
+/*
  * Re-lay ONE canonical flat weight set (P floats) into kernel layout (PK
  * floats).  Used for torch.nn.LSTM / nn.Linear weights of VanillaRNN and
  * VariationalRNN (vanilla_rnn.py:26-34, variational_rnn.py:37-52).

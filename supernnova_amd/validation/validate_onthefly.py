@@ -63,73 +63,57 @@ def featurize(df, st):
     order and contiguous; offsets[i]:offsets[i+1] are the rows of ids[i]."""
     df = _host_columns(df.copy(), st)
     filters = list(st.list_filters)
-    snid = df["SNID"].values
-    ids, inv = np.unique(snid, return_inverse=True)
-    mjd = df["MJD"].values.astype(np.float64)
-    order = np.lexsort((mjd, inv))                      # sort by (SNID, MJD)
-    inv, mjd = inv[order], mjd[order]
-    flux = df["FLUXCAL"].values.astype(np.float64)[order]
-    err = df["FLUXCALERR"].values.astype(np.float64)[order]
-    flt = df["FLT"].values[order]
-    n = len(mjd)
-    new_lc = np.ones(n, bool)
-    new_lc[1:] = inv[1:] != inv[:-1]
-    dt = np.diff(mjd, prepend=mjd[:1])
-    dt[new_lc] = 0.0
-    # 8-hour grouping: a row opens a new group when dt == 0 or it is > MIN_DT after the group's first time
-    grouped = np.empty(n)
-    last = 0.0
-    for i in range(n):                                  # sequential by definition (depends on the running group start)
-        if dt[i] == 0 or (mjd[i] - last) > MIN_DT:
-            grouped[i] = last = mjd[i]
-        else:
-            grouped[i] = grouped[i - 1]
-    fidx = np.full(n, -1)
-    for k, f in enumerate(filters):
-        fidx[flt == f] = k
-    keep = fidx >= 0                                    # filters the model does not know fill no column
-    # row key (curve, group); within a (key, filter) keep the lowest FLUXCALERR
-    gkey = np.unique(np.stack([inv, grouped], 1), axis=0, return_inverse=True)[1].reshape(-1)
-    n_rows = int(gkey.max()) + 1 if n else 0
-    F = len(filters)
-    fl = np.zeros((n_rows, F))
-    er = np.zeros((n_rows, F))
-    present = np.zeros((n_rows, F), bool)
-    sel = np.lexsort((err, fidx, gkey))                 # ascending error inside each (row, filter)
-    sel = sel[keep[sel]]
-    first = np.ones(len(sel), bool)
-    first[1:] = (gkey[sel][1:] != gkey[sel][:-1]) | (fidx[sel][1:] != fidx[sel][:-1])
-    pick = sel[first]
-    fl[gkey[pick], fidx[pick]] = flux[pick]
-    er[gkey[pick], fidx[pick]] = err[pick]
-    present[gkey[pick], fidx[pick]] = True
-    row_curve = np.zeros(n_rows, np.int64)
+    inv, ids = pd.factorize(df["SNID"].values, sort=True)     # ids sorted, inv = index into ids
+    ids = np.asarray(ids)
+    inv = np.ascontiguousarray(inv, dtype=np.int64)
+    mjd = np.ascontiguousarray(df["MJD"].values, dtype=np.float64)
+    flux = np.ascontiguousarray(df["FLUXCAL"].values, dtype=np.float64)
+    err = np.ascontiguousarray(df["FLUXCALERR"].values, dtype=np.float64)
+    fidx = np.ascontiguousarray(pd.Categorical(df["FLT"].values, categories=filters).codes, dtype=np.int64)  # -1: unknown
+    n, F = len(mjd), len(filters)
+    # Native passes (csrc/snn_featurize.hip): time order inside each light curve, the reference's sequential 8-hour
+    # grouping, the output row of every observation; then per (row, filter) the observation with the lowest
+    # FLUXCALERR (earliest on ties).  Filters the model does not know fill no column.
+    from .. import _lib
+    lib = _lib.load()
+    order, row_of, row_mjd_of = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n)
+    rows_per_curve = np.zeros(len(ids), np.int64)
+    n_rows = _lib.check(lib.snn_featurize_plan(n, len(ids), inv.ctypes.data, mjd.ctypes.data, MIN_DT, order.ctypes.data,
+                                               row_of.ctypes.data, row_mjd_of.ctypes.data, rows_per_curve.ctypes.data),
+                        "snn_featurize_plan")
+    fl, er = np.zeros((n_rows, F)), np.zeros((n_rows, F))
+    present = np.zeros((n_rows, F), np.uint8)
     row_mjd = np.zeros(n_rows)
-    row_curve[gkey] = inv
-    row_mjd[gkey] = grouped
+    _lib.check(lib.snn_featurize_fill(n, n_rows, F, order.ctypes.data, row_of.ctypes.data, row_mjd_of.ctypes.data,
+                                      flux.ctypes.data, err.ctypes.data, fidx.ctypes.data, fl.ctypes.data, er.ctypes.data,
+                                      present.ctypes.data, row_mjd.ctypes.data), "snn_featurize_fill")
+    present = present.astype(bool)
+    row_curve = np.repeat(np.arange(len(ids)), rows_per_curve)
     # a group that holds only filters the model does not know still survives the reference's pivot (its FLUXCAL_<f>
     # column exists there): zero fluxes, empty filter string, no one-hot bit (make_dataset.py:885-910)
     start = np.ones(n_rows, bool)
     start[1:] = row_curve[1:] != row_curve[:-1]
     gdt = np.diff(row_mjd, prepend=row_mjd[:1])
     gdt[start] = 0.0
-    combos = {c: i for i, c in enumerate(st.list_filters_combination)}
-    name = np.array(["".join(f for f, p in zip(filters, pr) if p) for pr in present])
+    # filter-combination name of a row = its present filters concatenated in list_filters order; as a bit mask here
+    bits = present @ (1 << np.arange(F))
+    combo_bits = {c: m for m in range(1 << F)
+                  for c in ["".join(f for k, f in enumerate(filters) if m >> k & 1)] if c in set(st.list_filters_combination)}
     cols = {f"FLUXCAL_{f}": fl[:, k] for k, f in enumerate(filters)}
     cols.update({f"FLUXCALERR_{f}": er[:, k] for k, f in enumerate(filters)})
     cols["delta_time"] = gdt
     host = [k for k in st.all_features if "HOST" in k]
     if host:
-        first_of = np.zeros(len(ids), np.int64)         # host values are per light curve: take the first row's
-        first_of[inv[::-1]] = np.arange(n)[::-1]
+        first_of = np.zeros(len(ids), np.int64)         # host values are per light curve: take its first row's (in time)
+        first_of[inv[order][::-1]] = order[::-1]
         for k in host:
-            cols[k] = df[k].values.astype(np.float64)[order][first_of][row_curve]
+            cols[k] = df[k].values.astype(np.float64)[first_of][row_curve]
     X = np.zeros((n_rows, len(st.all_features)), np.float32)
     for j, feat in enumerate(st.all_features):
         if feat in cols:
             X[:, j] = cols[feat].astype(np.float32)     # the reference casts float64 columns to float32 (:916-918)
-        elif feat in combos:
-            X[:, j] = name == feat
+        elif feat in combo_bits:
+            X[:, j] = bits == combo_bits[feat]
     live_ids = ids[np.unique(row_curve)] if n_rows else ids[:0]
     counts = np.bincount(row_curve, minlength=len(ids))[np.unique(row_curve)] if n_rows else np.zeros(0, np.int64)
     offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
