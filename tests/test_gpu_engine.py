@@ -267,7 +267,8 @@ def test_unsupported_shapes_fail_loudly():
 @pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 70, 40), (26, 5, "standard", 2, 97, 17),
                                             (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
                                             (42, 2, "mean", 2, 50, 12), (78, 14, "mean", 2, 40, 30),
-                                            (24, 2, "mean", 2, 21, 40)])
+                                            (24, 2, "mean", 2, 21, 40), (24, 2, "mean", 2, 1, 1),
+                                            (24, 2, "mean", 2, 97, 300), (78, 14, "standard", 2, 33, 300)])
 def test_split_precision_vs_oracle(prec, D, C, pool, L, N, T):
     """SNN_PREC_BF16X3: every fp32 product rebuilt from six bf16 piece products on the bf16 matrix pipe;
     SNN_PREC_F16X2: from three fp16 piece products.  Same parity bar as the fp32 kernels (logits 5e-6 absolute,
