@@ -32,33 +32,34 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
                                                      const int64_t* __restrict__ tile_off,
                                                      __bf16* __restrict__ xp)
 {
+    // one thread per 16-byte output word: 8 consecutive features of one curve at one step, read as 32 contiguous
+    // bytes, written as NPC full words (lanes of a wave write consecutive words)
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
-    const int64_t step_bf16 = (int64_t)XB * NPC * 64 * 8;
-    __bf16* dst = xp + tile_off[tile] / ((int64_t)Dp * SNN_TILE) * step_bf16;
-    for (int idx = threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x) {
-        const int t = idx >> 5, c = idx & 31;
+    const int64_t step_u4 = (int64_t)XB * NPC * 64;
+    uint4* dst = reinterpret_cast<uint4*>(xp) + tile_off[tile] / ((int64_t)Dp * SNN_TILE) * step_u4;
+    for (int idx = threadIdx.x; idx < T * XB * 64; idx += blockDim.x) {
+        const int t = idx / (XB * 64), r = idx - t * (XB * 64), b = r >> 6, lp = r & 63, c = lp & 31;
         const int pos = tile * SNN_TILE + c;
         const int orig = order[pos];
         const bool live = orig >= 0 && t < len_sorted[pos];
         const int on = live ? orig : 0;
         const float* src = x + (int64_t)t * stride_t + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
-        __bf16* o = dst + (int64_t)t * step_bf16;
-        for (int k = 0; k < 16 * XB; ++k) {
-            const float v = (live && k < D) ? src[k] : 0.0f;
-            const int64_t a = ((((int64_t)(k >> 4) * NPC) * 64) + ((k >> 3) & 1) * 32 + c) * 8 + (k & 7);
-            if (NPC == 3) {
-                __bf16 h, m, l;
-                split3(v, h, m, l);
-                o[a] = h;
-                o[a + 64 * 8] = m;
-                o[a + 2 * 64 * 8] = l;
-            } else {
-                _Float16 h, l;
-                split2(v, h, l);
-                reinterpret_cast<_Float16*>(o)[a] = h;
-                reinterpret_cast<_Float16*>(o)[a + 64 * 8] = l;
-            }
+        const int k0 = 16 * b + 8 * (lp >> 5);
+        uint4* o = dst + (int64_t)t * step_u4 + (int64_t)b * NPC * 64 + lp;
+        if (NPC == 3) {
+            alignas(16) __bf16 h[8], m[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split3((live && k0 + e < D) ? src[k0 + e] : 0.0f, h[e], m[e], l[e]);
+            o[0] = *reinterpret_cast<const uint4*>(h);
+            o[64] = *reinterpret_cast<const uint4*>(m);
+            o[128] = *reinterpret_cast<const uint4*>(l);
+        } else {
+            alignas(16) _Float16 h[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2((live && k0 + e < D) ? src[k0 + e] : 0.0f, h[e], l[e]);
+            o[0] = *reinterpret_cast<const uint4*>(h);
+            o[64] = *reinterpret_cast<const uint4*>(l);
         }
     }
 }
