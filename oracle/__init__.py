@@ -22,6 +22,7 @@ class OracleCfg(ctypes.Structure):
         ("bidirectional", ctypes.c_int32),
         ("nb_classes", ctypes.c_int32),
         ("pool", ctypes.c_int32),
+        ("cell", ctypes.c_int32),
     ]
 
 
@@ -68,9 +69,12 @@ def _c32(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
 
 
-def make_cfg(input_size, hidden_size, num_layers=2, bidirectional=True, nb_classes=2, pool="mean"):
+CELLS = {"lstm": 0, "gru": 1, "rnn": 2}
+
+
+def make_cfg(input_size, hidden_size, num_layers=2, bidirectional=True, nb_classes=2, pool="mean", cell="lstm"):
     return OracleCfg(int(input_size), int(hidden_size), int(num_layers), int(bool(bidirectional)),
-                     int(nb_classes), 0 if pool == "mean" else 1)
+                     int(nb_classes), 0 if pool == "mean" else 1, CELLS[cell])
 
 
 def param_count(cfg):

@@ -51,7 +51,11 @@ typedef struct {
     int32_t bidirectional; /* 0/1 */
     int32_t nb_classes;    /* C */
     int32_t pool;          /* 0 = mean, 1 = standard */
+    int32_t cell;          /* 0 = lstm, 1 = gru, 2 = rnn (tanh): VanillaRNN's layer_type, vanilla_rnn.py:26-32 */
 } snn_oracle_cfg;
+
+/* gate rows per hidden unit: LSTM i,f,g,o; GRU r,z,n; RNN one pre-activation (torch.nn.{LSTM,GRU,RNN} layouts) */
+static int n_gates(const snn_oracle_cfg *c) { return c->cell == 1 ? 3 : c->cell == 2 ? 1 : 4; }
 
 static real sigm(real x) { return (real)1 / ((real)1 + (real)exp(-(double)x)); }
 static real tanhr(real x) { return (real)tanh((double)x); }
@@ -77,7 +81,7 @@ int64_t snn_oracle_param_count(const snn_oracle_cfg *c)
     int dirs = c->bidirectional ? 2 : 1;
     int64_t H = c->hidden_size, p = 0;
     for (int l = 0; l < c->num_layers; ++l)
-        p += dirs * (4 * H * (layer_in(c, l) + H + 2));
+        p += dirs * (n_gates(c) * H * (layer_in(c, l) + H + 2));
     p += (int64_t)c->nb_classes * snn_oracle_feat(c) + c->nb_classes;
     return p;
 }
@@ -105,7 +109,8 @@ int snn_oracle_forward(const snn_oracle_cfg *cfg, const float *x, int T, int B,
     const int D = cfg->input_size, H = cfg->hidden_size, L = cfg->num_layers;
     const int dirs = cfg->bidirectional ? 2 : 1, C = cfg->nb_classes;
     const int F = (int)snn_oracle_feat(cfg);
-    const int G = 4 * H;
+    const int G = n_gates(cfg) * H;
+    real *gih = (real *)malloc(sizeof(real) * G), *ghh = (real *)malloc(sizeof(real) * G);
     int maxI = D > dirs * H ? D : dirs * H;
     real *in = (real *)malloc(sizeof(real) * (size_t)T * maxI);
     real *out = (real *)malloc(sizeof(real) * (size_t)T * dirs * H);
@@ -149,12 +154,26 @@ int snn_oracle_forward(const snn_oracle_cfg *cfg, const float *x, int T, int B,
                         }
                         hg += (real)b_hh[r];
                         gates[r] = ig + hg;
+                        gih[r] = ig;
+                        ghh[r] = hg;
                     }
                     for (int j = 0; j < H; ++j) {
-                        real ig = sigm(gates[j]), fg = sigm(gates[H + j]);
-                        real gg = tanhr(gates[2 * H + j]), og = sigm(gates[3 * H + j]);
-                        c[j] = fg * c[j] + ig * gg;
-                        h[j] = og * tanhr(c[j]);
+                        if (cfg->cell == 1) {
+                            /* torch.nn.GRU: r, z, n rows; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1-z) n + z h */
+                            real rg = sigm(gates[j]), zg = sigm(gates[H + j]);
+                            real ng = tanhr(gih[2 * H + j] + rg * ghh[2 * H + j]);
+                            c[j] = ((real)1 - zg) * ng + zg * h[j];
+                        } else if (cfg->cell == 2) {
+                            c[j] = tanhr(gates[j]);                       /* torch.nn.RNN, nonlinearity tanh */
+                        } else {
+                            real ig = sigm(gates[j]), fg = sigm(gates[H + j]);
+                            real gg = tanhr(gates[2 * H + j]);
+                            c[j] = fg * c[j] + ig * gg;
+                        }
+                    }
+                    for (int j = 0; j < H; ++j) {
+                        if (cfg->cell == 0) h[j] = sigm(gates[3 * H + j]) * tanhr(c[j]);
+                        else h[j] = c[j];                                /* GRU / RNN: c held the new h of all units */
                         out[(size_t)t * dirs * H + d * H + j] = h[j];
                     }
                 }
@@ -205,6 +224,7 @@ int snn_oracle_forward(const snn_oracle_cfg *cfg, const float *x, int T, int B,
                 probs[(size_t)b * C + q] = (float)((real)exp((double)(lg[q] - mx)) / z);
         }
     }
+    free(gih); free(ghh);
     free(in); free(out); free(gates); free(h); free(c); free(hn); free(feat); free(lg);
     return 0;
 }

@@ -65,3 +65,20 @@ def test_bayesian_golden(tag, D, H, C, pool):
     assert abs(oracle.kl(cfg, w, mu[:n], sigma) - g["kl_mfe"]) / abs(g["kl_mfe"]) < 2e-6
     o = oracle.forward(cfg, g["x"], g["lengths"], np.concatenate([w, mu[n:]]))
     np.testing.assert_allclose(o["logits"], g["logits_mfe"], atol=LOGIT_ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+@pytest.mark.parametrize("pool,D,C", [("mean", 24, 2), ("standard", 26, 3)])
+def test_gru_and_rnn_layer_types_golden(cell, pool, D, C):
+    """VanillaRNN with layer_type gru / rnn (vanilla_rnn.py:26-32): the oracle's GRU and tanh-RNN cells against
+    the reference's torch.nn.GRU / torch.nn.RNN logits, packed and dense input."""
+    g = load_golden(f"g9_{cell}_{pool}")
+    cfg = oracle.make_cfg(D, 32, 2, True, C, pool, cell=cell)
+    w = flat(g["sd"], layout.vanilla_keys(2, 2))
+    assert w.size == oracle.param_count(cfg)
+    o = oracle.forward(cfg, g["x"], g["lengths"], w)
+    np.testing.assert_allclose(o["logits"], g["logits"], atol=LOGIT_ATOL, rtol=0)
+    np.testing.assert_allclose(o["probs"], g["probs"], rtol=1e-5, atol=0)
+    T, B, _ = g["x"].shape
+    od = oracle.forward(cfg, g["x"], np.full(B, T), w)
+    np.testing.assert_allclose(od["logits"], g["logits_dense"], atol=LOGIT_ATOL, rtol=0)

@@ -577,6 +577,34 @@ def g7_onthefly():
     save("g7_onthefly", **out)
 
 
+# ---------------------------------------------------------------- G9 GRU / RNN layer types
+def flat_rnn_generic(sd, L, dirs):
+    """Same key order as flat_vanilla (torch's _flat_weights); row counts follow the cell (3H for GRU, H for RNN)."""
+    return flat_vanilla(sd, L, dirs)
+
+
+def g9_layer_types():
+    """VanillaRNN with layer_type gru / rnn (vanilla_rnn.py:26-32: torch.nn.GRU / torch.nn.RNN), both poolings,
+    packed and dense input; the C oracle's GRU / tanh-RNN cells are checked against the reference here."""
+    for cell, seed in (("gru", 31), ("rnn", 32)):
+        for pool, C, D in (("mean", 2, 24), ("standard", 3, 26)):
+            torch.manual_seed(seed + (pool == "standard"))
+            st = settings(layer_type=cell, rnn_output_option=pool, nb_classes=C)
+            m = build(vanilla_rnn.VanillaRNN, D, st)
+            m.eval()
+            x, lengths = make_batch(seed, 19, 37, D)
+            with torch.no_grad():
+                lo = m(pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths)))
+                lo_dense = m(torch.from_numpy(x))
+            sdn = sd_np(m)
+            cfg = oracle.make_cfg(D, st.hidden_dim, st.num_layers, st.bidirectional, C, pool, cell=cell)
+            w = flat_rnn_generic(sdn, 2, 2)
+            check(f"{cell} {pool} packed", oracle.forward(cfg, x, lengths, w)["logits"], lo.numpy())
+            check(f"{cell} {pool} dense", oracle.forward(cfg, x, np.full(37, 19), w)["logits"], lo_dense.numpy())
+            save(f"g9_{cell}_{pool}", sd=sdn, x=x, lengths=lengths, logits=lo.numpy(), probs=softmax(lo),
+                 logits_dense=lo_dense.numpy())
+
+
 # ---------------------------------------------------------------- G8 SWAG
 def g8_swag():
     """utils/swag_utils.py SwagModel around a VanillaRNN: 6 parameter snapshots (a random walk standing in for SGD
@@ -626,7 +654,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
     if "g0" in which:
         g0_init()
     if "g1" in which:
@@ -643,3 +671,5 @@ if __name__ == "__main__":
         g7_onthefly()
     if "g8" in which:
         g8_swag()
+    if "g9" in which:
+        g9_layer_types()
