@@ -57,7 +57,21 @@ typedef struct snn_cfg {
     int32_t nb_classes;    /* C  */
     int32_t pool;          /* SNN_POOL_* */
     int32_t precision;     /* SNN_PREC_*: arithmetic of the gate products in snn_lstm_forward */
+    int32_t cell;          /* SNN_CELL_*: settings.layer_type (vanilla_rnn.py:30-40) */
 } snn_cfg;
+
+/*
+ * SNN_CELL_LSTM  torch.nn.LSTM stack (gate blocks i, f, g, o): every entry point.
+ * SNN_CELL_GRU   torch.nn.GRU stack (gate blocks r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
+ *                h' = (1 - z) * n + z * h), and
+ * SNN_CELL_RNN   torch.nn.RNN stack with tanh: VanillaRNN's other two layer types.  Inference only, SNN_PREC_F32,
+ *                no masks, hidden sizes 32 and 64: snn_param_count / snn_kparam_count / snn_prepare_weights(_multi) /
+ *                snn_lstm_forward take them (canonical tensors have 3H resp. H rows); the training and Bayesian entry
+ *                points return SNN_ERR_UNSUPPORTED.
+ */
+#define SNN_CELL_LSTM 0
+#define SNN_CELL_GRU 1
+#define SNN_CELL_RNN 2
 
 /*
  * SNN_PREC_F32     every product in fp32 (v_mfma_f32_32x32x2_f32): the default, and the only mode of the

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SNN_HIP_LIB") or os.path.join(_HERE, "libsnn_hip.so")
 
 SNN_POOL_MEAN, SNN_POOL_STANDARD = 0, 1
 SNN_PREC_F32, SNN_PREC_BF16X3, SNN_PREC_F16X2 = 0, 1, 2
+SNN_CELL_LSTM, SNN_CELL_GRU, SNN_CELL_RNN = 0, 1, 2
 SNN_MASK_NONE, SNN_MASK_ARRAYS, SNN_MASK_PHILOX = 0, 1, 2
 BBB_EPS, BBB_MFE, BBB_PHILOX = 0, 1, 2
 TILE = 32
@@ -20,7 +21,8 @@ TILE = 32
 class SnnCfg(ctypes.Structure):
     _fields_ = [("input_size", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
                 ("num_layers", ctypes.c_int32), ("bidirectional", ctypes.c_int32),
-                ("nb_classes", ctypes.c_int32), ("pool", ctypes.c_int32), ("precision", ctypes.c_int32)]
+                ("nb_classes", ctypes.c_int32), ("pool", ctypes.c_int32), ("precision", ctypes.c_int32),
+                ("cell", ctypes.c_int32)]
 
 
 class SnnPrior(ctypes.Structure):

@@ -213,9 +213,10 @@ int snn_make_layout(const snn_cfg* cfg, SnnLayout* y)
 {
     if (!cfg) { snn_set_error("cfg is NULL"); return SNN_ERR_ARG; }
     if (snn_layout_init(y, cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->bidirectional,
-                        cfg->nb_classes, cfg->pool, cfg->precision) != 0) {
-        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d precision=%d (need H %% 8 == 0, 1 <= L <= %d)", cfg->input_size,
-                      cfg->hidden_size, cfg->num_layers, cfg->nb_classes, cfg->pool, cfg->precision, SNN_MAX_LAYERS);
+                        cfg->nb_classes, cfg->pool, cfg->precision, cfg->cell) != 0) {
+        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d precision=%d cell=%d (need H %% 8 == 0, 1 <= L <= %d; GRU / RNN "
+                      "cells in SNN_PREC_F32 only)", cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->nb_classes,
+                      cfg->pool, cfg->precision, cfg->cell, SNN_MAX_LAYERS);
         return SNN_ERR_ARG;
     }
     return SNN_OK;
@@ -249,7 +250,7 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 
 // ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; };
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; };
 struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; };
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
@@ -265,6 +266,11 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
     if (y.prec != 0) return nullptr;   // the bf16 x 3 kernels have their own launcher
     const FwdSmallEntry* e = y.H == 32 ? snn_fwd_small_h32(y.KKI[0], y.dirs)
                            : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
+    if (e && y.cell != 0) {   // GRU / tanh RNN: un-masked inference kernel only
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr, nullptr, false};
+        return &ent;
+    }
+    if (y.cell != 0) return nullptr;
     if (e) {
         ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false};
         return &ent;
@@ -359,7 +365,7 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
                          float* kl_terms, hipStream_t st, int64_t mu_stride = 0)
 {
-    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0)  // padding words exist: define them
+    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0 || y.cell != 0)  // padding words exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
     hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
                        offset, prior, wk, kl ? kl_terms : nullptr, mu_stride);
@@ -404,6 +410,7 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_bbb_sample"))) return rc;
     if (!mu || !rho || !wk || !prior || S < 1 || S > 65535) {
         snn_set_error("snn_bbb_sample: null pointer or n_samples out of [1, 65535]");
         return SNN_ERR_ARG;
@@ -551,11 +558,11 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
         return rc ? rc : g.ws_bytes;
     }
     const FwdEntry* e = find_fwd(y);
-    if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (!e) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d cell=%d", y.H, y.D, y.dirs, y.cell); return SNN_ERR_UNSUPPORTED; }
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
     FwdGeom g, gt;
     rc = fwd_geom(y, e->fn, e->big, max_T, &g);
-    if (!rc && !e->big) {
+    if (!rc && !e->big && y.cell == 0) {
         rc = fwd_geom(y, e->fn_masked, false, max_T, &gt);
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
         if (!rc) rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
@@ -601,8 +608,9 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if (train && (rc = snn_lstm_only(y, "snn_lstm_forward_train"))) return rc;
     const FwdEntry* e = find_fwd(y);
-    if (!e && y.prec == 0) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
+    if (!e && y.prec == 0) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d cell=%d", y.H, y.D, y.dirs, y.cell); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !workspace || (!out_logits && !out_probs)) {
         snn_set_error("snn_lstm_forward: null pointer");
         return SNN_ERR_ARG;
@@ -630,11 +638,11 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     const bool masked = masks && masks->mode != SNN_MASK_NONE;
     fwd_kernel_t fn = train ? e->fn_train : masked ? e->fn_masked : e->fn;
-    if (!fn) { snn_set_error("no training kernel for H=%d", y.H); return SNN_ERR_UNSUPPORTED; }
+    if (!fn) { snn_set_error("no %s kernel for H=%d cell=%d", train ? "training" : "masked", y.H, y.cell); return SNN_ERR_UNSUPPORTED; }
     if (e->big && !train && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)
     bool pair = false;
-    if (!train && !masked && !e->big && n_tiles > 1) {
+    if (!train && !masked && !e->big && n_tiles > 1 && y.cell == 0) {
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
         fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs);
         if (fp) { fn = fp; pair = true; }
@@ -686,6 +694,7 @@ extern "C" int64_t snn_train_tape_floats(const snn_cfg* cfg, int32_t n_tiles, in
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_train_tape_floats"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_train_tape_floats: bad sizes"); return SNN_ERR_ARG; }
     return tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F) * n_tiles;
 }

@@ -26,7 +26,8 @@ struct PhaseCfg {
 //   FIRST: input comes from the packed x tile; else from the previous layer's output.
 //   TRAIN: activations go to the tape (which also carries the layer outputs, unmasked; the
 //          between-layer mask is then applied by the consumer while staging).
-template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED>
+//   CELL:  0 LSTM, 1 GRU, 2 tanh RNN (snn_layout.h: the weight image has the LSTM's 4 row groups for every cell).
+template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED, int CELL = 0>
 __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
                                           int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
 {
@@ -182,14 +183,25 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         float* tp = TRAIN ? tape_ld + (int64_t)t * tape_step_floats(H) + j0 * 32 + c.cl : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float ig = snn_sigmoid(acc[u]);
-            const float fg = snn_sigmoid(acc[4 + u]);
-            const float gg = snn_tanh(acc[8 + u]);
-            const float og = snn_sigmoid(acc[12 + u]);
+            float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, hv;
+            if (CELL == 1) {
+                // torch.nn.GRU: r, z from the summed pre-activations; group 2 carries W_in x + b_in, group 3 W_hn h + b_hn
+                const float rg = snn_sigmoid(acc[u]);
+                const float zg = snn_sigmoid(acc[4 + u]);
+                const float ng = snn_tanh(fmaf(rg, acc[12 + u], acc[8 + u]));
+                hv = fmaf(zg, hst[u] - ng, ng);   // (1 - z) n + z h
+            } else if (CELL == 2) {
+                hv = snn_tanh(acc[u]);
+            } else {
+            ig = snn_sigmoid(acc[u]);
+            fg = snn_sigmoid(acc[4 + u]);
+            gg = snn_tanh(acc[8 + u]);
+            og = snn_sigmoid(acc[12 + u]);
             // explicit contraction: every copy of the loop body (peeled last step, TRAIN variant) must round the
             // same way, so a curve's result does not depend on the tile it lands in
-            const float cn = fmaf(fg, cst[u], __fmul_rn(ig, gg));
-            const float hv = og * snn_tanh(cn);
+            cn = fmaf(fg, cst[u], __fmul_rn(ig, gg));
+            hv = og * snn_tanh(cn);
+            }
             cst[u] = valid ? cn : cst[u];
             hst[u] = valid ? hv : hst[u];
             outv[u] = valid ? hv : 0.0f;
@@ -269,7 +281,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     __syncthreads();  // also publishes this phase's y / tape stores to the workgroup
 }
 
-template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED>
+template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED, int CELL = 0>
 __global__ void __launch_bounds__(H * 8, ((TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) * 32 / H > 0 ? ((TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) * 32 / H : 1)
 lstm_fwd_kernel(const FwdParams p)
 {
@@ -319,11 +331,11 @@ lstm_fwd_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    run_phase<H, KKI0, DIRS, true, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w,
+                    run_phase<H, KKI0, DIRS, true, TRAIN, MASKED, CELL>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w,
                                                                   xin, hb, part, logit, bl);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    run_phase<H, KKI1, DIRS, false, TRAIN, MASKED>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w,
+                    run_phase<H, KKI1, DIRS, false, TRAIN, MASKED, CELL>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w,
                                                                    xin, hb, part, logit, bl);
                 }
             }
@@ -353,10 +365,11 @@ lstm_fwd_kernel(const FwdParams p)
 
 // ---- instantiation lists ------------------------------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; };
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; };
 #define SNN_FWD_ENTRY(H, K, Dd)                                                                       \
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
-     lstm_fwd_kernel<H, K, Dd, true, true>}
+     lstm_fwd_kernel<H, K, Dd, true, true>, lstm_fwd_kernel<H, K, Dd, false, false, 1>,         \
+     lstm_fwd_kernel<H, K, Dd, false, false, 2>}
 // layer-0 k-step buckets of snn_layout.h (D <= 24, 26, 48, 76, 78), both direction counts
 #define SNN_FWD_ENTRIES(H)                                                                              \
     SNN_FWD_ENTRY(H, 12, 2), SNN_FWD_ENTRY(H, 13, 2), SNN_FWD_ENTRY(H, 24, 2), SNN_FWD_ENTRY(H, 38, 2), \

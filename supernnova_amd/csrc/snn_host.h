@@ -6,3 +6,11 @@
 
 void snn_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int snn_make_layout(const snn_cfg* cfg, SnnLayout* y);
+// the training and Bayesian entry points exist for the LSTM cell only (the reference trains GRU / tanh-RNN stacks through
+// torch.nn.GRU / torch.nn.RNN, vanilla_rnn.py:30-40; here those cells have an inference kernel)
+static inline int snn_lstm_only(const SnnLayout& y, const char* fn)
+{
+    if (y.cell == 0) return SNN_OK;
+    snn_set_error("%s: cell %d (1 GRU, 2 RNN) is inference-only (snn_prepare_weights* + snn_lstm_forward in SNN_PREC_F32)", fn, y.cell);
+    return SNN_ERR_UNSUPPORTED;
+}

@@ -76,10 +76,10 @@ __device__ __forceinline__ TensorGeom tensor_geom(const SnnLayout& y, int tau)
         g.ld = tau >> 2;
         g.kind = tau & 3;
         const int l = g.ld / y.dirs;
-        if (g.kind == 0) { g.cbase = y.c_wih[g.ld]; g.cols = y.I[l]; g.n = (int64_t)4 * y.H * y.I[l]; }
-        else if (g.kind == 1) { g.cbase = y.c_whh[g.ld]; g.cols = y.H; g.n = (int64_t)4 * y.H * y.H; }
-        else if (g.kind == 2) { g.cbase = y.c_bih[g.ld]; g.cols = 1; g.n = 4 * y.H; }
-        else { g.cbase = y.c_bhh[g.ld]; g.cols = 1; g.n = 4 * y.H; }
+        if (g.kind == 0) { g.cbase = y.c_wih[g.ld]; g.cols = y.I[l]; g.n = (int64_t)y.NG * y.H * y.I[l]; }
+        else if (g.kind == 1) { g.cbase = y.c_whh[g.ld]; g.cols = y.H; g.n = (int64_t)y.NG * y.H * y.H; }
+        else if (g.kind == 2) { g.cbase = y.c_bih[g.ld]; g.cols = 1; g.n = y.NG * y.H; }
+        else { g.cbase = y.c_bhh[g.ld]; g.cols = 1; g.n = y.NG * y.H; }
     } else if (tau == 4 * nld) {
         g.ld = 0; g.kind = 4; g.cbase = y.c_head_w; g.cols = y.F; g.n = (int64_t)y.C * y.F;
     } else {
@@ -98,13 +98,13 @@ __device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const Tensor
     if (g.kind <= 1) {
         const int R = (int)(i / g.cols), col = (int)(i - (int64_t)R * g.cols);
         const int gate = R / H, j = R - gate * H;
-        const int w = j >> 3, r = gate * 8 + (j & 7);
+        const int w = j >> 3, r = snn_row_group(y.cell, gate, g.kind == 1) * 8 + (j & 7);
         const int k = g.kind == 0 ? col : 2 * y.KKI[l] + col;
         const int kk = k >> 1, lane = (k & 1) * 32 + r;
         return y.k_A[g.ld] + ((int64_t)(w * y.KK[l] + kk)) * 64 + lane;
     }
     const int R = (int)i, gate = R / H, j = R - gate * H;
-    const int w = j >> 3, hf = (j & 7) >> 2, ii = gate * 4 + (j & 3);
+    const int w = j >> 3, hf = (j & 7) >> 2, ii = snn_row_group(y.cell, gate, g.kind == 3) * 4 + (j & 3);
     return y.k_bias[g.ld] + (g.kind == 3 ? y.NW * 32 : 0) + (w * 2 + hf) * 16 + ii;
 }
 

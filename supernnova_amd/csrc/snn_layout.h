@@ -44,6 +44,12 @@ struct SnnLayout {
     //   2 log2 e for g), see snn_split2_scale.
     int prec;
     int NPC;   // pieces per value: 3 (precision 1), 2 (precision 2)
+    // recurrent cell (snn_cfg.cell): 0 LSTM, 1 GRU, 2 tanh RNN.  NG = gate blocks of the canonical tensors (4 / 3 / 1).
+    // The kernel image always has the LSTM's 4 row groups per hidden unit, so one MFMA tiling serves all cells:
+    //   GRU   group 0 = r (W_ir | W_hr), 1 = z (W_iz | W_hz), 2 = n, input part (W_in | 0), 3 = n, hidden part
+    //         (0 | W_hn); biases alike (b_in in group 2, b_hn in group 3), so that n = tanh(a2 + r * a3);
+    //   RNN   group 0 = (W_ih | W_hh), groups 1-3 zero.
+    int cell, NG;
     int XB[SNN_MAX_LAYERS], NB[SNN_MAX_LAYERS];
 };
 
@@ -59,12 +65,21 @@ static inline int snn_kki0_bucket(int D)
     return (D + 1) / 2;
 }
 
-static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool, int prec = 0)
+// kernel row group of canonical gate block `gate` of a hidden-side tensor (w_hh, b_hh) / input-side tensor
+static inline __host__ __device__ int snn_row_group(int cell, int gate, bool hidden_side)
+{
+    return (cell == 1 && gate == 2 && hidden_side) ? 3 : gate;
+}
+
+static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, int C, int pool, int prec = 0, int cell = 0)
 {
     if (D < 1 || H < 8 || (H % 8) != 0 || L < 1 || L > SNN_MAX_LAYERS || C < 1 || pool < 0 || pool > 1 || prec < 0 ||
-        prec > 2 || (prec >= 1 && (H % 16) != 0))
+        prec > 2 || (prec >= 1 && (H % 16) != 0) || cell < 0 || cell > 2 || (cell != 0 && prec != 0))
         return -1;
     y->prec = prec;
+    y->cell = cell;
+    y->NG = cell == 0 ? 4 : cell == 1 ? 3 : 1;
+    const int NG = y->NG;
     y->NPC = prec == 2 ? 2 : 3;
     y->D = D; y->H = H; y->L = L; y->dirs = bidir ? 2 : 1; y->C = C; y->pool = pool;
     y->F = pool == 0 ? y->dirs * H : y->dirs * H * L;
@@ -79,10 +94,10 @@ static inline int snn_layout_init(SnnLayout* y, int D, int H, int L, int bidir, 
         y->NB[l] = y->XB[l] + H / 16;
         for (int d = 0; d < y->dirs; ++d) {
             int ld = l * y->dirs + d;
-            y->c_wih[ld] = c; c += (int64_t)4 * H * y->I[l];
-            y->c_whh[ld] = c; c += (int64_t)4 * H * H;
-            y->c_bih[ld] = c; c += 4 * H;
-            y->c_bhh[ld] = c; c += 4 * H;
+            y->c_wih[ld] = c; c += (int64_t)NG * H * y->I[l];
+            y->c_whh[ld] = c; c += (int64_t)NG * H * H;
+            y->c_bih[ld] = c; c += NG * H;
+            y->c_bhh[ld] = c; c += NG * H;
             y->k_A[ld] = k; k += prec == 0 ? (int64_t)y->NW * y->KK[l] * 64 : (int64_t)y->NW * y->NB[l] * y->NPC * 64 * 4;
             y->k_bias[ld] = k; k += (int64_t)2 * y->NW * 32;
         }

@@ -76,6 +76,7 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_lstm_backward_workspace_bytes"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
     const BwdEntry* fused = find_bwd(y);
     if (use_split_path(y, fused, n_tiles)) {
@@ -96,6 +97,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_lstm_backward"))) return rc;
     const BwdEntry* e = find_bwd(y);
     if (!e && !snn_bwd_big_supported(y)) { snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !tape || !dlogits || !dflat || !workspace) {
@@ -211,6 +213,7 @@ extern "C" int snn_bbb_backward(const snn_cfg* cfg, const float* mu, const float
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_bbb_backward"))) return rc;
     if (!mu || !rho || !prior || !kl_terms || !dw || !dmu || !drho || mode < 0 || mode > 2 || (mode == 0 && !eps)) {
         snn_set_error("snn_bbb_backward: null pointer or bad mode");
         return SNN_ERR_ARG;

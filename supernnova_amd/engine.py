@@ -40,12 +40,14 @@ class Config:
     nb_classes: int = 2
     pool: str = "mean"
     precision: str = "f32"      # "f32" | "bf16x3" | "f16x2" (include/snn_hip.h: SNN_PREC_*; the last two inference only)
+    cell: str = "lstm"          # settings.layer_type: "lstm" | "gru" | "rnn" (SNN_CELL_*; gru / rnn inference only, f32)
 
     @property
     def c(self):
         return L.SnnCfg(self.input_size, self.hidden_size, self.num_layers, int(bool(self.bidirectional)),
                         self.nb_classes, L.SNN_POOL_MEAN if self.pool == "mean" else L.SNN_POOL_STANDARD,
-                        {"f32": L.SNN_PREC_F32, "bf16x3": L.SNN_PREC_BF16X3, "f16x2": L.SNN_PREC_F16X2}[self.precision])
+                        {"f32": L.SNN_PREC_F32, "bf16x3": L.SNN_PREC_BF16X3, "f16x2": L.SNN_PREC_F16X2}[self.precision],
+                        {"lstm": L.SNN_CELL_LSTM, "gru": L.SNN_CELL_GRU, "rnn": L.SNN_CELL_RNN}[self.cell])
 
     def with_precision(self, precision):
         from dataclasses import replace

@@ -33,16 +33,19 @@ def _dirs(bidirectional):
     return 2 if bidirectional else 1
 
 
-class _LSTMParams(nn.Module):
-    """Parameter container with torch.nn.LSTM's names, shapes, registration order and
-    reset_parameters() (U(-1/sqrt(H), 1/sqrt(H)) over parameters in order)."""
+_GATES = {"lstm": 4, "gru": 3, "rnn": 1}     # gate blocks of torch.nn.LSTM / GRU / RNN parameters
 
-    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+
+class _LSTMParams(nn.Module):
+    """Parameter container with torch.nn.LSTM's (layer_type gru / rnn: torch.nn.GRU's / torch.nn.RNN's) names,
+    shapes, registration order and reset_parameters() (U(-1/sqrt(H), 1/sqrt(H)) over parameters in order)."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional, layer_type="lstm"):
         super().__init__()
         self.input_size, self.hidden_size = input_size, hidden_size
         self.num_layers, self.bidirectional = num_layers, bidirectional
         dirs = _dirs(bidirectional)
-        G = 4 * hidden_size
+        G = _GATES[layer_type] * hidden_size
         for l in range(num_layers):
             I = input_size if l == 0 else hidden_size * dirs
             for d in range(dirs):
@@ -67,9 +70,10 @@ class _WeightDropParams(nn.Module):
         self.module = m
 
 
-def _check_settings(settings):
-    if settings.layer_type != "lstm":
-        raise ValueError(f"supernnova_amd implements layer_type 'lstm' only, got {settings.layer_type!r}")
+def _check_settings(settings, layer_types=("lstm",)):
+    if settings.layer_type not in layer_types:
+        raise ValueError(f"supernnova_amd implements layer_type {' / '.join(layer_types)} for this model, "
+                         f"got {settings.layer_type!r}")
     if settings.rnn_output_option not in ("mean", "standard"):
         raise ValueError(f"unknown rnn_output_option {settings.rnn_output_option!r}")
 
@@ -91,8 +95,8 @@ class _HipRNN(nn.Module):
         cfg = self.cfg.with_precision(self.inference_precision)
         return cfg if cfg.supported() else self.cfg
 
-    def _init_common(self, input_size, settings):
-        _check_settings(settings)
+    def _init_common(self, input_size, settings, layer_types=("lstm",)):
+        _check_settings(settings, layer_types)
         self.input_size = input_size
         self.layer_type = settings.layer_type
         self.output_size = settings.nb_classes
@@ -102,7 +106,7 @@ class _HipRNN(nn.Module):
         self.use_cuda = settings.use_cuda
         self.rnn_output_option = settings.rnn_output_option
         self.cfg = E.Config(input_size, self.hidden_size, self.num_layers, self.bidirectional,
-                            self.output_size, self.rnn_output_option)
+                            self.output_size, self.rnn_output_option, cell=self.layer_type)
         self._pflat = None
         self.dp_curve_base = 0   # data-parallel: global index of this rank's first curve (per-curve Philox masks)
 
@@ -187,7 +191,11 @@ class _HipRNN(nn.Module):
         return int(torch.empty((), dtype=torch.int64).random_().item())
 
     def _use_train_path(self):
-        return self.training and torch.is_grad_enabled()
+        train = self.training and torch.is_grad_enabled()
+        if train and self.layer_type != "lstm":
+            raise L.SnnError(f"layer_type {self.layer_type!r} has inference kernels only: call .eval() or run under "
+                             "torch.no_grad() (training kernels exist for 'lstm')")
+        return train
 
     def _train_forward(self, x, masks_fn, eps=None, mean_field_inference=False):
         """Differentiable forward (autograd.Function over the HIP train/backward kernels)."""
@@ -200,6 +208,8 @@ class _HipRNN(nn.Module):
     def fused_train_step(self, x, target, optimizer, kl_scale=0.0, eps=None, masks=None):
         """One training step without autograd (utils/training_utils.py:508-525 in five launches):
         forward-train, CE + dlogits, BPTT, (BBB backward), fused Adam.  Returns the loss (device scalar)."""
+        if self.layer_type != "lstm":
+            raise L.SnnError(f"layer_type {self.layer_type!r} has inference kernels only (training kernels exist for 'lstm')")
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
@@ -251,9 +261,10 @@ class _HipRNN(nn.Module):
 class VanillaRNN(_HipRNN):
     def __init__(self, input_size, settings):
         super().__init__()
-        self._init_common(input_size, settings)
+        # layer_type gru / rnn (vanilla_rnn.py:26-32: getattr(torch.nn, layer_type.upper())): inference kernels only
+        self._init_common(input_size, settings, ("lstm", "gru", "rnn"))
         self.dropout = settings.dropout
-        self.rnn_layer = _LSTMParams(input_size, self.hidden_size, self.num_layers, self.bidirectional)
+        self.rnn_layer = _LSTMParams(input_size, self.hidden_size, self.num_layers, self.bidirectional, self.layer_type)
         self.output_dropout_layer = nn.Dropout(self.dropout)
         self.output_layer = nn.Linear(self.last_input_size, self.output_size)
 

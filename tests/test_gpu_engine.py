@@ -391,3 +391,58 @@ def test_f16x2_masks_refused_for_wide_inputs():
     masks = E.Masks(mode=2, which=0xF, dropout=0.1, seed=3)
     with pytest.raises(_lib.SnnError):
         _run(E, cfg, x, lengths, E.prepare_weights(cfg, _t(w)), 2, masks)
+
+
+# ---------------------------------------------------------------- layer_type gru / rnn (vanilla_rnn.py:26-32)
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+@pytest.mark.parametrize("pool,D,C", [("mean", 24, 2), ("standard", 26, 3)])
+def test_gru_rnn_golden(cell, pool, D, C):
+    """torch.nn.GRU / torch.nn.RNN stacks of the reference's VanillaRNN: fixture logits / probabilities, packed and dense."""
+    E = _eng()
+    g = load_golden(f"g9_{cell}_{pool}")
+    cfg = E.Config(D, 32, 2, True, C, pool, cell=cell)
+    w = flat(g["sd"], layout.vanilla_keys(2, 2))
+    assert cfg.supported() and cfg.P == w.size
+    wk = E.prepare_weights(cfg, _t(w))
+    lo, pr = _run(E, cfg, g["x"], g["lengths"], wk, 1)
+    _check(lo[0], pr[0], g["logits"], g["probs"])
+    T, B, _ = g["x"].shape
+    lo, pr = _run(E, cfg, g["x"], np.full(B, T), wk, 1)
+    _check(lo[0], pr[0], g["logits_dense"])
+
+
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+@pytest.mark.parametrize("D,H,L,bidir,C,pool", [(24, 32, 2, True, 2, "mean"), (26, 64, 1, False, 3, "standard"),
+                                                (44, 32, 3, False, 14, "mean"), (78, 64, 2, True, 20, "standard")])
+def test_gru_rnn_vs_oracle_ragged(cell, D, H, L, bidir, C, pool):
+    """Seeded ragged batches (lengths 1..T, N not a multiple of 32, several weight sets in one launch) vs the C oracle."""
+    E = _eng()
+    S, N, T = 3, 139, 45
+    cfg = E.Config(D, H, L, bidir, C, pool, cell=cell)
+    ocfg = oracle.make_cfg(D, H, L, bidir, C, pool, cell=cell)
+    assert cfg.P == oracle.param_count(ocfg)
+    g = np.random.default_rng(11)
+    ws = g.uniform(-0.2, 0.2, (S, cfg.P)).astype(np.float32)   # logits of order 1: LOGIT_ATOL is an absolute bound
+    x, lengths = make_curves(12, N, T, D, min_len=1)
+    wk = E.prepare_weights_multi(cfg, _t(ws))
+    lo, pr = _run(E, cfg, x, lengths, wk, S)
+    for s in range(S):
+        o = oracle.forward(ocfg, x, lengths, ws[s])
+        _check(lo[s], pr[s], o["logits"], o["probs"])
+
+
+def test_gru_rnn_are_inference_only():
+    """The training / Bayesian / split-precision entry points refuse the GRU and RNN cells with a clear error."""
+    E = _eng()
+    from supernnova_amd import _lib as L
+    cfg = E.Config(24, 32, 2, True, 2, "mean", cell="gru")
+    assert not cfg.with_precision("f16x2").supported()
+    x, lengths = make_curves(3, 40, 12, 24, min_len=1)
+    plan = E.Plan(cfg, lengths, DEV)
+    xp = E.pack_x(cfg, plan, _t(x))
+    wk = E.prepare_weights(cfg, torch.zeros(cfg.P, device=DEV))
+    with pytest.raises(L.SnnError, match="inference-only"):
+        E.lstm_forward_train(cfg, plan, xp, wk)
+    masks = E.Masks(mode=L.SNN_MASK_PHILOX, which=8, dropout=0.1, seed=1)
+    with pytest.raises(L.SnnError, match="masked"):
+        E.lstm_forward(cfg, plan, xp, wk, 1, masks=masks)

@@ -172,3 +172,25 @@ def test_inference_precision_through_the_module_api(model, fast):
     for u, v in zip(outs["f32"], outs[fast]):
         assert rel_err(softmax_np(u) if u is outs["f32"][0] else u, softmax_np(v) if v is outs[fast][0] else v) < PROB_RTOL
     np.testing.assert_allclose(outs[fast][1], outs[fast][2], rtol=0, atol=0)   # same launch, two entry points
+
+
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+@pytest.mark.parametrize("pool,kw,D", [("mean", {}, 24), ("standard", dict(rnn_output_option="standard", nb_classes=3), 26)])
+def test_vanilla_module_gru_rnn(cell, pool, kw, D):
+    """VanillaRNN with layer_type gru / rnn (vanilla_rnn.py:26-32): the reference's state dict loads key for key and
+    the eval forward reproduces its logits; the training paths refuse with a clear error."""
+    from supernnova_amd import _lib as L
+    g = load_golden(f"g9_{cell}_{pool}")
+    rnn = _model("vanilla", g["sd"], D, layer_type=cell, **kw)
+    ref_cls = torch.nn.GRU if cell == "gru" else torch.nn.RNN
+    ref = ref_cls(D, 32, num_layers=2, bidirectional=True)
+    assert [(k, tuple(v.shape)) for k, v in rnn.rnn_layer.state_dict().items()] == \
+        [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+    with torch.no_grad():
+        _close(rnn(_packed(g)), g["logits"])
+        _close(rnn(torch.from_numpy(g["x"]).to(DEV)), g["logits_dense"])
+        probs = rnn.forward_mc(_packed(g), 2).cpu().numpy()
+    assert rel_err(probs[:, 0], g["probs"]) < PROB_RTOL and np.array_equal(probs[:, 0], probs[:, 1])
+    rnn.train()
+    with pytest.raises(L.SnnError, match="inference kernels only"):
+        rnn(_packed(g))
