@@ -226,15 +226,22 @@ extern "C" int snn_bbb_backward(const snn_cfg* cfg, const float* mu, const float
 
 // ============================================================================
 // Cross-entropy (mean over the batch) and its gradient w.r.t. the logits
-// (nn.CrossEntropyLoss() at utils/training_utils.py:515): one workgroup, fixed-order sum.
+// (nn.CrossEntropyLoss() at utils/training_utils.py:515).  Up to CE_MAX_BLOCKS workgroups, each a fixed-order
+// partial sum in fp64 over its curves; the workgroup that finishes last adds the partials in index order, so the
+// loss does not depend on scheduling.  The partials live in a file-scope device array: calls that overlap on one
+// GPU (different streams) would race -- a training step is one stream.
 // ============================================================================
+#define CE_MAX_BLOCKS 256
+static __device__ double g_ce_partial[CE_MAX_BLOCKS];
+static __device__ unsigned int g_ce_done;
+
 __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const float* __restrict__ logits,
                                                           const int64_t* __restrict__ target, float scale,
                                                           float* __restrict__ loss, float* __restrict__ dlogits)
 {
     __shared__ double sh[4];
     double acc = 0.0;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
         const float* lg = logits + (int64_t)n * C;
         float mx = -INFINITY;
         for (int q = 0; q < C; ++q) mx = fmaxf(mx, lg[q]);
@@ -250,7 +257,22 @@ __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const f
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *loss = (float)((sh[0] + sh[1] + sh[2] + sh[3]) / (double)N);
+    if (threadIdx.x == 0) {
+        const double part = sh[0] + sh[1] + sh[2] + sh[3];
+        if (gridDim.x == 1) {
+            *loss = (float)(part / (double)N);
+        } else {
+            __hip_atomic_store(&g_ce_partial[blockIdx.x], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int done = __hip_atomic_fetch_add(&g_ce_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == gridDim.x - 1) {
+                double tot = 0.0;
+                for (unsigned int b = 0; b < gridDim.x; ++b)
+                    tot += __hip_atomic_load(&g_ce_partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *loss = (float)(tot / (double)N);
+                __hip_atomic_store(&g_ce_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+            }
+        }
+    }
 }
 
 extern "C" int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float* logits, const int64_t* target,
@@ -260,7 +282,9 @@ extern "C" int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float* logit
         snn_set_error("snn_ce_loss_grad: null pointer or bad size");
         return SNN_ERR_ARG;
     }
-    hipLaunchKernelGGL(ce_loss_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, n_classes, logits, target,
+    // one workgroup per 1024 curves (4 per thread): a batch of 128 stays a single workgroup, exactly as before
+    const int blocks = std::min(CE_MAX_BLOCKS, (n + 1023) / 1024);
+    hipLaunchKernelGGL(ce_loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, n_classes, logits, target,
                        grad_scale, loss, dlogits);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;

@@ -162,13 +162,32 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) wT[kk] = A[kk * 64];
     }
-    float dc[UPT], dhr[UPT];
+    float dc[UPT], dhr[UPT], dfm[UPT];
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
         const int j = jg + 8 * i;
         dc[i] = 0.0f;
         dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * dirs) + ld) * 32 + c] : 0.0f;
+        dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + j) * 32 + c] * inv_len : 0.0f;
     }
+    // The tape rows (and dy) of a step are fetched one step ahead: the recurrence is a latency chain, and an
+    // un-prefetched global load per step was most of it.  Rows t < T of the tape and of dy are always written
+    // (forward / bwd_dx store every step of the tile), so the fetch needs no length test.
+    float n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cn[UPT], n_dy[UPT];
+    auto fetch = [&](int t) {
+        const float* tq = tape_ld + (int64_t)t * ts + c;
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int j = jg + 8 * i;
+            n_ig[i] = tq[(0 * H + j) * 32];
+            n_fg[i] = tq[(1 * H + j) * 32];
+            n_gg[i] = tq[(2 * H + j) * 32];
+            n_og[i] = tq[(3 * H + j) * 32];
+            n_cn[i] = tq[(4 * H + j) * 32];
+            n_dy[i] = dy ? dy[(int64_t)t * H * 32 + j * 32 + c] : 0.0f;
+        }
+    };
+    if (T > 0) fetch(d == 0 ? T - 1 : 0);
 
     for (int sb = 0; sb < T; ++sb) {
         const int step = T - 1 - sb;
@@ -176,26 +195,28 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
         const int tp = d == 0 ? t - 1 : t + 1;
         const bool valid = t < len;
         const bool prev_live = step > 0 && tp < len;
-        const float* tq = tape_ld + (int64_t)t * ts;
-        const float* tqp = tape_ld + (int64_t)tp * ts;
+        float ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], dyv[UPT];
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cn[i] = n_cn[i]; dyv[i] = n_dy[i];
+        }
+        if (step > 0) fetch(tp);   // n_cn is then c of the previous step: the cell state this step started from
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             const int j = jg + 8 * i;
             float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
             if (valid) {
                 float dh = dhr[i];
-                if (dy) dh += dy[(int64_t)t * H * 32 + j * 32 + c];
-                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfeat[(d * H + j) * 32 + c] * inv_len;
-                const float ig = tq[(0 * H + j) * 32 + c], fg = tq[(1 * H + j) * 32 + c], gg = tq[(2 * H + j) * 32 + c];
-                const float og = tq[(3 * H + j) * 32 + c], cn = tq[(4 * H + j) * 32 + c];
-                const float cp = prev_live ? tqp[(4 * H + j) * 32 + c] : 0.0f;
-                const float tc = snn_tanh(cn);
-                const float dct = dc[i] + dh * og * (1.0f - tc * tc);
-                dao = dh * tc * og * (1.0f - og);
-                dai = dct * gg * ig * (1.0f - ig);
-                daf = dct * cp * fg * (1.0f - fg);
-                dag = dct * ig * (1.0f - gg * gg);
-                dc[i] = dct * fg;
+                if (dy) dh += dyv[i];
+                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
+                const float cp = prev_live ? n_cn[i] : 0.0f;
+                const float tc = snn_tanh(cn[i]);
+                const float dct = dc[i] + dh * og[i] * (1.0f - tc * tc);
+                dao = dh * tc * og[i] * (1.0f - og[i]);
+                dai = dct * gg[i] * ig[i] * (1.0f - ig[i]);
+                daf = dct * cp * fg[i] * (1.0f - fg[i]);
+                dag = dct * ig[i] * (1.0f - gg[i] * gg[i]);
+                dc[i] = dct * fg[i];
             }
             dGl[(0 * H + j) * 32 + c] = dai;
             dGl[(1 * H + j) * 32 + c] = daf;
@@ -235,23 +256,27 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
 }
 
 // ---- dy of the layer below ------------------------------------------------------------------------------
-template <int H>
+// TSW = time steps per wave.  A workgroup covers 4 steps; with fewer than 4 output tiles (H = 32: dirs * H / 32 = 1 or 2)
+// the steps are split over the waves instead of leaving waves idle: wave w takes tile w % MTX, steps (w / MTX) * TSW ...
+template <int H, int TSW>
 __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, int n_tchunks)
 {
-    constexpr int TS = 4;   // time steps per workgroup: every W_ih^T operand load feeds TS MFMAs
+    constexpr int TS = 4;   // time steps per workgroup: every W_ih^T operand load feeds TSW MFMAs
     const SnnLayout& y = p.lay;
     const int dirs = y.dirs;
-    const int tile = blockIdx.x / n_tchunks, t0 = (blockIdx.x - tile * n_tchunks) * TS;
+    const int tile = blockIdx.x / n_tchunks, tw = (blockIdx.x - tile * n_tchunks) * TS;
     const int T = p.tile_T[tile];
-    if (t0 >= T) return;
+    if (tw >= T) return;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
     const int MTX = dirs * H / 32;
     const int orig = p.order[tile * SNN_TILE + cl];
     const bool masked = p.mk.mode != SNN_MASK_NONE;
-    for (int mt = w; mt < MTX; mt += 4) {
-        f32x16 acc[TS];
+    const int mt0 = TSW == TS ? w : w % MTX, mt_step = TSW == TS ? 4 : MTX * (TS / TSW);   // launch: MTX * (TS / TSW) == 4
+    const int t0 = tw + (TSW == TS ? 0 : (w / MTX) * TSW);
+    for (int mt = mt0; mt < MTX; mt += mt_step) {
+        f32x16 acc[TSW];
 #pragma unroll
-        for (int s = 0; s < TS; ++s)
+        for (int s = 0; s < TSW; ++s)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
         for (int d = 0; d < dirs; ++d) {
@@ -260,23 +285,23 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
             const float* B = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t0) * 4 * H * 32 + lane;
             // operands stream from L2: issue a batch of KB k-steps' loads, then their MFMAs (steps beyond the
             // tile's last one read the next step's rows of the same buffer and are never stored)
-            constexpr int KB = 16;
+            constexpr int KB = TSW == TS ? 16 : 32;
             for (int k0 = 0; k0 < 2 * H; k0 += KB) {
-                float a[KB], b[TS][KB];
+                float a[KB], b[TSW][KB];
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
                     a[k] = A[(k0 + k) * 64];
 #pragma unroll
-                    for (int s = 0; s < TS; ++s) b[s][k] = (t0 + s < p.max_T) ? B[(int64_t)s * 4 * H * 32 + (k0 + k) * 64] : 0.0f;
+                    for (int s = 0; s < TSW; ++s) b[s][k] = (t0 + s < p.max_T) ? B[(int64_t)s * 4 * H * 32 + (k0 + k) * 64] : 0.0f;
                 }
 #pragma unroll
                 for (int k = 0; k < KB; ++k)
 #pragma unroll
-                    for (int s = 0; s < TS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[s][k], acc[s], 0, 0, 0);
+                    for (int s = 0; s < TSW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[s][k], acc[s], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int s = 0; s < TS; ++s) {
+        for (int s = 0; s < TSW; ++s) {
             const int t = t0 + s;
             if (t < T) {
 #pragma unroll
@@ -470,7 +495,9 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
         HIP_CHECK(hipGetLastError());
         if (l > 0) {
             const int n_tchunks = (p.max_T + 3) / 4;
-            hipLaunchKernelGGL(bwd_dx_kernel<H>, dim3(p.n_tiles * n_tchunks), dim3(256), 0, st, p, l, n_tchunks);
+            const int mtx = y.dirs * H / 32;
+            auto dx = mtx == 1 ? bwd_dx_kernel<H, 1> : mtx == 2 ? bwd_dx_kernel<H, 2> : bwd_dx_kernel<H, 4>;
+            hipLaunchKernelGGL(dx, dim3(p.n_tiles * n_tchunks), dim3(256), 0, st, p, l, n_tchunks);
             HIP_CHECK(hipGetLastError());
         }
         const int ntn = (H + y.I[l] + 1 + 31) / 32;

@@ -281,3 +281,20 @@ def test_train_step_larger_hidden_sizes_vs_port(model, H):
     assert abs(float(loss) - float(ref_loss)) < 3e-6 * max(1.0, abs(float(ref_loss)))
     for k, p in rnn.named_parameters():
         _grad_check(p.grad.cpu().numpy(), ref_sd[k].grad.numpy(), k)
+
+
+@pytest.mark.parametrize("N,C", [(1, 2), (1024, 2), (1025, 3), (70001, 14), (400000, 2)])
+def test_ce_loss_grad_any_batch_size(N, C):
+    """snn_ce_loss_grad (nn.CrossEntropyLoss, utils/training_utils.py:515) from one workgroup to the 256-workgroup cap,
+    two calls in a row (the cross-workgroup counter must re-arm), against torch in fp64."""
+    from supernnova_amd import engine as E
+    g = torch.Generator().manual_seed(N)
+    logits = (3 * torch.randn(N, C, generator=g)).to(DEV)
+    target = torch.randint(0, C, (N,), generator=g).to(DEV)
+    ref_in = logits.double().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, target)
+    ref.backward()
+    for _ in range(2):
+        ce, dlogits = E.ce_loss_grad(logits, target)
+        assert abs(float(ce) - float(ref)) < 2e-7 * max(1.0, abs(float(ref)))
+        assert float((dlogits.double() - ref_in.grad).abs().max()) < 2e-7 / N * max(1, N // 1000) + 1e-12
