@@ -195,6 +195,41 @@ __global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ te
     kl[s] = acc;
 }
 
+// Head of the per-layer training forward (lstm_fwd_train_layer_kernel): per curve, the per-wave partial logits of the
+// phases that feed the head, added in the persistent kernel's order ((l, d) outer, wave inner, from 0.0f), then bias
+// (+ softmax): the same fp32 additions, so the same bits.
+__global__ void __launch_bounds__(64) head_combine_kernel(const FwdParams p, int H, int dirs, int64_t k_head_b,
+                                                         const float* __restrict__ head_part)
+{
+    const int tile = blockIdx.x, cl = threadIdx.x;
+    if (cl >= 32) return;
+    const int orig = p.order[tile * SNN_TILE + cl];
+    if (orig < 0) return;
+    const int NW = H / 8, n_ld = p.L * dirs;
+    const float* bo = p.wk + k_head_b;
+    const int64_t o = (int64_t)orig * p.os_n;
+    float mx = -INFINITY;
+    for (int pass = 0; pass < 2; ++pass) {   // pass 0: logits + max; pass 1: probabilities (only when asked for)
+        float z = 0.0f;
+        if (pass == 1) {
+            if (!p.out_probs) break;
+            for (int q = 0; q < p.C; ++q) z += expf(p.out_probs[o + q] - mx);
+        }
+        for (int q = 0; q < p.C; ++q) {
+            if (pass == 1) { p.out_probs[o + q] = __fdiv_rn(expf(p.out_probs[o + q] - mx), z); continue; }
+            float a = 0.0f;
+            for (int ld = (p.pool == SNN_POOL_STANDARD ? 0 : n_ld - dirs); ld < n_ld; ++ld) {
+                const float* pp = head_part + ((int64_t)tile * n_ld + ld) * (NW * p.C * 32) + q * 32 + cl;
+                for (int w = 0; w < NW; ++w) a += pp[(int64_t)w * p.C * 32];
+            }
+            const float lg = a + bo[q];
+            mx = fmaxf(mx, lg);
+            if (p.out_logits) p.out_logits[o + q] = lg;
+            if (p.out_probs) p.out_probs[o + q] = lg;   // parked; normalised in pass 1
+        }
+    }
+}
+
 // ============================================================================
 // host side
 // ============================================================================
@@ -250,8 +285,9 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 
 // ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; };
-struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; };
+typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; fwd_layer_kernel_t fn_train_layer; };
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; fwd_layer_kernel_t fn_train_layer; };
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
@@ -267,17 +303,17 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
     const FwdSmallEntry* e = y.H == 32 ? snn_fwd_small_h32(y.KKI[0], y.dirs)
                            : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
     if (e && y.cell != 0) {   // GRU / tanh RNN: un-masked inference kernel only
-        ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr, nullptr, false};
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr, nullptr, false, nullptr};
         return &ent;
     }
     if (y.cell != 0) return nullptr;
     if (e) {
-        ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false};
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false, e->fn_train_layer};
         return &ent;
     }
     // hidden sizes whose weights do not fit the register file: two-pass kernel
     if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, false)) {
-        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true};
+        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true, nullptr};
         return &ent;
     }
     return nullptr;
@@ -669,6 +705,18 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     p.nbuf = g.nbuf;
     p.tape = tape; p.tape_tile = tape_tile;
     hipStream_t st = (hipStream_t)stream;
+    // small training batches: one launch per layer with the two directions side by side (snn_fwd_small.h)
+    const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * y.NW * y.C * 32;
+    static const bool no_layerwise = getenv("SNN_NO_LAYERWISE") != nullptr;   // A/B measurements only
+    if (train && e->fn_train_layer && !no_layerwise && n_tiles * y.dirs <= 2 * g.cus && 256 + part_bytes <= workspace_bytes) {
+        float* head_part = (float*)((char*)workspace + 256);
+        HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_train_layer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        for (int l = 0; l < y.L; ++l)
+            hipLaunchKernelGGL(e->fn_train_layer, dim3(n_tiles * y.dirs), dim3(g.threads), g.lds, st, p, l, head_part);
+        hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, y.H, y.dirs, y.k_head_b, head_part);
+        HIP_CHECK(hipGetLastError());
+        return SNN_OK;
+    }
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
     const int64_t n_items = (int64_t)(pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);

@@ -363,13 +363,77 @@ lstm_fwd_kernel(const FwdParams p)
 }
 
 
+// ---- training forward of ONE layer, a workgroup per (tile, direction) ------------------------------------
+// Small batches are a latency chain: 4 tiles of a 128-curve batch occupy 4 workgroups for L * DIRS * T steps in the
+// persistent kernel above.  The two directions of a layer are independent, so this variant runs them side by side
+// (grid = n_tiles * DIRS, one launch per layer: the launch boundary is the wait for both directions of the layer
+// below) and halves the chain.  Same run_phase, same tape; each phase's per-wave head partials go to `head_part`
+// ([tile][ld][NW][C][32]) and head_combine_kernel (snn_forward.hip) adds them in the persistent kernel's order, so
+// the logits are bit-identical to the one-launch path.
+template <int H, int KKI0, int DIRS>
+__global__ void __launch_bounds__(H * 8, 2 * 32 / H > 0 ? 2 * 32 / H : 1)
+lstm_fwd_train_layer_kernel(const FwdParams p, int l, float* __restrict__ head_part)
+{
+    constexpr int NT = H * 8;
+    constexpr int KKI1 = DIRS * H / 2;
+    constexpr int ROWS = (2 * KKI0 > 2 * KKI1) ? 2 * KKI0 : 2 * KKI1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdParams& y = p;
+    constexpr int NW = H / 8;
+    constexpr int BLK0 = NW * (KKI0 + H / 2) * 64 + 2 * NW * 32;
+    constexpr int BLK1 = NW * (KKI1 + H / 2) * 64 + 2 * NW * 32;
+    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
+    float* xin = smem;
+    float* hb = xin + 2 * ROWS * 32;
+    float* part = hb + 2 * H * 32;
+    float* logit = part + NW * y.C * 32;
+    float* bl = logit + y.C * 32;
+
+    ItemCtx c;
+    c.tid = threadIdx.x;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.cl = c.lane & 31;
+    c.hf = c.lane >> 5;
+    c.ybase = nullptr;   // TRAIN: layer outputs travel through the tape
+    c.tile = blockIdx.x / DIRS;
+    const int d = blockIdx.x - c.tile * DIRS;
+    c.s = 0;
+    c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+    const int pos = c.tile * SNN_TILE + c.cl;
+    c.len = p.len_sorted[pos];
+    c.orig = p.order[pos];
+    c.wks = p.wk;
+    c.tape = p.tape + (int64_t)c.tile * p.tape_tile;
+    for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
+    __syncthreads();
+    if (l == 0) {
+        const int kA = d * BLK0;
+        run_phase<H, KKI0, DIRS, true, true, true>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
+    } else {
+        const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
+        run_phase<H, KKI1, DIRS, false, true, true>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
+    }
+    if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {   // this phase feeds the head: `part` holds its per-wave partials
+        float* dst = head_part + ((int64_t)c.tile * (y.L * DIRS) + l * DIRS + d) * (NW * y.C * 32);
+        for (int idx = c.tid; idx < NW * y.C * 32; idx += NT) dst[idx] = part[idx];
+    }
+}
+
 // ---- instantiation lists ------------------------------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; };
+typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; fwd_layer_kernel_t fn_train_layer; };
+template <int H, int K, int Dd>
+constexpr fwd_layer_kernel_t train_layer_kernel()
+{
+    if constexpr (Dd == 2) return lstm_fwd_train_layer_kernel<H, K, Dd>;
+    else return nullptr;   // one direction: nothing to run side by side
+}
 #define SNN_FWD_ENTRY(H, K, Dd)                                                                       \
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
      lstm_fwd_kernel<H, K, Dd, true, true>, lstm_fwd_kernel<H, K, Dd, false, false, 1>,         \
-     lstm_fwd_kernel<H, K, Dd, false, false, 2>}
+     lstm_fwd_kernel<H, K, Dd, false, false, 2>, train_layer_kernel<H, K, Dd>()}
 // layer-0 k-step buckets of snn_layout.h (D <= 24, 26, 48, 76, 78), both direction counts
 #define SNN_FWD_ENTRIES(H)                                                                              \
     SNN_FWD_ENTRY(H, 12, 2), SNN_FWD_ENTRY(H, 13, 2), SNN_FWD_ENTRY(H, 24, 2), SNN_FWD_ENTRY(H, 38, 2), \

@@ -101,30 +101,32 @@ __global__ void __launch_bounds__(256) head_dfeat_kernel(const Bwd2Params p)
     }
 }
 
-// dW_out[q][f] = sum over curves (fixed order) dlogits[curve][q] feat[curve][f];  db_out[q] = sum dlogits
+// dW_out[q][f] = sum over curves dlogits[curve][q] feat[curve][f];  db_out[q] = sum dlogits.  One workgroup per output
+// element: thread k adds sorted positions k, k + 256, ... in order, then a fixed shuffle / LDS tree -- the order depends
+// on the batch only, never on scheduling.
 __global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p)
 {
+    __shared__ float sh[4];
     const SnnLayout& y = p.lay;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= y.C * y.F + y.C) return;
+    const int idx = blockIdx.x;   // grid = C * F + C
     const int64_t feat0 = (int64_t)y.L * y.dirs * p.max_T * tape_step_floats(y.H);
+    const int npos = p.n_tiles * SNN_TILE;
+    const bool is_w = idx < y.C * y.F;
+    const int q = is_w ? idx / y.F : idx - y.C * y.F, f = is_w ? idx - q * y.F : 0;
     float s = 0.0f;
-    if (idx < y.C * y.F) {
-        const int q = idx / y.F, f = idx - q * y.F;
-        for (int tile = 0; tile < p.n_tiles; ++tile) {
-            const float* feat = p.tape + (int64_t)tile * p.tape_tile + feat0 + f * 32;
-            for (int c = 0; c < 32; ++c) {
-                const int o = p.order[tile * SNN_TILE + c];
-                if (o >= 0) s = fmaf(p.dlogits[(int64_t)o * y.C + q], feat[c], s);
-            }
-        }
-        float* dst = p.dflat + y.c_head_w + idx;
-        *dst = (p.accumulate ? *dst : 0.0f) + s;
-    } else {
-        const int q = idx - y.C * y.F;
-        for (int o = 0; o < p.n_curves; ++o) s += p.dlogits[(int64_t)o * y.C + q];
-        float* dst = p.dflat + y.c_head_b + q;
-        *dst = (p.accumulate ? *dst : 0.0f) + s;
+    for (int pos = threadIdx.x; pos < npos; pos += 256) {
+        const int o = p.order[pos];
+        if (o < 0) continue;
+        const float dl = p.dlogits[(int64_t)o * y.C + q];
+        s = is_w ? fmaf(dl, p.tape[(int64_t)(pos >> 5) * p.tape_tile + feat0 + f * 32 + (pos & 31)], s) : s + dl;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* dst = p.dflat + (is_w ? y.c_head_w + idx : y.c_head_b + q);
+        *dst = (p.accumulate ? *dst : 0.0f) + (((sh[0] + sh[1]) + sh[2]) + sh[3]);
     }
 }
 
@@ -458,7 +460,10 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     g->dG_floats = (int64_t)n_tiles * y.dirs * max_T * 4 * y.H * 32;
     g->dy_floats = (int64_t)n_tiles * y.dirs * max_T * y.H * 32;
     const int64_t total = (int64_t)n_tiles * max_T;
-    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, total / 8));
+    // weight-gradient partial sums: one slab of P floats per chunk of tile-steps; up to 256 chunks while the slabs stay
+    // under 64 MB (small models, large batches), never fewer than the 64 the large models ran with
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(256, ((int64_t)64 << 20) / ((int64_t)sizeof(float) * y.P)));
+    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, total / 8));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
 }
@@ -480,7 +485,7 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     const int n_ld = y.L * y.dirs;
     hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
     hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dw_kernel, dim3((y.C * y.F + y.C + 255) / 256), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p);
     HIP_CHECK(hipGetLastError());
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);

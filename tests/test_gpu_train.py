@@ -298,3 +298,32 @@ def test_ce_loss_grad_any_batch_size(N, C):
         ce, dlogits = E.ce_loss_grad(logits, target)
         assert abs(float(ce) - float(ref)) < 2e-7 * max(1.0, abs(float(ref)))
         assert float((dlogits.double() - ref_in.grad).abs().max()) < 2e-7 / N * max(1, N // 1000) + 1e-12
+
+
+@pytest.mark.parametrize("pool,C,masked", [("mean", 2, False), ("standard", 5, True)])
+def test_layerwise_training_forward_is_bit_identical_to_the_persistent_kernel(pool, C, masked):
+    """Small batches run the training forward one launch per layer with both directions side by side
+    (lstm_fwd_train_layer_kernel + head_combine_kernel); large ones run the persistent kernel.  The same curves give
+    the same logits bit for bit either way (same additions in the same order), and the same parameter gradients from
+    the tapes the two paths leave."""
+    from supernnova_amd import engine as E
+    from util import make_curves
+    cfg = E.Config(24, 32, 2, True, C, pool)
+    n_small, n_big, T = 100, 4200, 30          # 4 tiles (layer-wise path) vs 132 tiles (> half the CUs: persistent kernel)
+    x, lengths = make_curves(21, n_big, T, 24, min_len=1)
+    lengths[:n_small] = np.maximum(lengths[:n_small], 2)
+    w = np.random.default_rng(4).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    wk = E.prepare_weights(cfg, _t(w))
+    mk = (lambda: E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=77, mid_T=1)) if masked else (lambda: None)
+    out = []
+    for n in (n_small, n_big):
+        plan = E.Plan(cfg, lengths[:n], DEV)
+        xp = E.pack_x(cfg, plan, _t(x[:, :n]))
+        logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
+        dlog = torch.zeros_like(logits)
+        dlog[:n_small] = torch.linspace(-1, 1, n_small * C, device=DEV).view(n_small, C)
+        dflat = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk())
+        out.append((logits[:n_small].cpu().numpy(), dflat.cpu().numpy()))
+    assert np.array_equal(out[0][0], out[1][0])
+    # the gradients add the same per-curve terms in a different tile order: equal to summation rounding
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-5 * np.abs(out[1][1]).max())
