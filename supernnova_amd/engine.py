@@ -92,10 +92,13 @@ class Plan:
         self.n_curves = int(lengths.size)
         self.n_tiles = (self.n_curves + L.TILE - 1) // L.TILE
         npad = self.n_tiles * L.TILE
-        self.order = np.empty(npad, np.int32)
-        self.len_sorted = np.empty(npad, np.int32)
-        self.tile_T = np.empty(self.n_tiles, np.int32)
-        self.tile_off = np.empty(self.n_tiles + 1, np.int64)
+        # the four plan arrays are views of one host buffer, so the device copy is ONE transfer (to())
+        a, b = 8 * (self.n_tiles + 1), 4 * npad
+        self._host = np.empty(a + 2 * b + 4 * self.n_tiles, np.uint8)
+        self.tile_off = self._host[:a].view(np.int64)
+        self.order = self._host[a:a + b].view(np.int32)
+        self.len_sorted = self._host[a + b:a + 2 * b].view(np.int32)
+        self.tile_T = self._host[a + 2 * b:].view(np.int32)
         i32 = ctypes.POINTER(ctypes.c_int32)
         L.check(L.load().snn_plan_build(
             ctypes.byref(cfg.c), lengths.ctypes.data_as(i32), self.n_curves,
@@ -116,10 +119,12 @@ class Plan:
 
     def to(self, device):
         self.device = torch.device(device)
-        self.d_order = torch.from_numpy(self.order).to(self.device)
-        self.d_len_sorted = torch.from_numpy(self.len_sorted).to(self.device)
-        self.d_tile_T = torch.from_numpy(self.tile_T).to(self.device)
-        self.d_tile_off = torch.from_numpy(self.tile_off).to(self.device)
+        d = torch.from_numpy(self._host).to(self.device)
+        a, b = self.tile_off.nbytes, self.order.nbytes
+        self.d_tile_off = d[:a].view(torch.int64)
+        self.d_order = d[a:a + b].view(torch.int32)
+        self.d_len_sorted = d[a + b:a + 2 * b].view(torch.int32)
+        self.d_tile_T = d[a + 2 * b:].view(torch.int32)
         return self
 
 

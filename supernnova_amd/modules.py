@@ -70,6 +70,30 @@ class _WeightDropParams(nn.Module):
         self.module = m
 
 
+def unpack_packed_sequence(x):
+    """pad_packed_sequence (vanilla_rnn.py:75-76) in three device operations instead of one copy per time step:
+    zeros, one host-built row map, one index_copy_.  Returns (padded (T, B, D) float32 in the original batch order,
+    lengths int32 numpy (B,) in the original order) -- the same values pad_packed_sequence returns."""
+    bs = x.batch_sizes.numpy().astype(np.int64)
+    T, B, D = bs.size, int(bs[0]), x.data.size(-1)
+    total = int(bs.sum())
+    start = np.zeros(T, np.int64)
+    np.cumsum(bs[:-1], out=start[1:])
+    t_idx = np.repeat(np.arange(T, dtype=np.int64), bs)
+    b_idx = np.arange(total, dtype=np.int64) - start[t_idx]          # sorted position of each packed row
+    lengths = np.searchsorted(-bs, -np.arange(B, dtype=np.int64), side="left").astype(np.int32)   # steps with bs > b
+    if x.sorted_indices is not None:
+        si = x.sorted_indices.cpu().numpy()
+        b_idx = si[b_idx]
+        lens = np.empty_like(lengths)
+        lens[si] = lengths
+        lengths = lens
+    rows = torch.from_numpy(t_idx * B + b_idx).to(x.data.device, non_blocking=True)
+    padded = torch.zeros((T * B, D), dtype=torch.float32, device=x.data.device)
+    padded.index_copy_(0, rows, x.data.float())
+    return padded.view(T, B, D), lengths
+
+
 def _check_settings(settings, layer_types=("lstm",)):
     if settings.layer_type not in layer_types:
         raise ValueError(f"supernnova_amd implements layer_type {' / '.join(layer_types)} for this model, "
@@ -172,8 +196,7 @@ class _HipRNN(nn.Module):
             if x.data.size(-1) != self.input_size:
                 raise RuntimeError("input.size(-1) must be equal to input_size. Expected {}, got {}".format(
                     self.input_size, x.data.size(-1)))
-            padded, lens = pad_packed_sequence(x)
-            lengths = lens.numpy().astype(np.int32)
+            padded, lengths = unpack_packed_sequence(x)
         else:
             if x.dim() != 3:
                 raise RuntimeError(f"input must have 3 dimensions, got {x.dim()}")

@@ -219,3 +219,22 @@ def test_prediction_dataframes_match_the_reference_layout():
     np.testing.assert_allclose(agg["all_class0_median"].values, med.numpy()[order, 0], rtol=1e-6)
     np.testing.assert_allclose(agg["all_class0_std"].values, std.numpy()[order, 0], rtol=1e-5)
     assert np.array_equal(agg["target"].values, d["target"][order, 0])
+
+
+def test_unpack_packed_sequence_equals_pad_packed_sequence():
+    """The modules' PackedSequence unpacking (three device operations) returns what torch's pad_packed_sequence
+    (vanilla_rnn.py:75-76) returns: sorted and enforce_sorted=False inputs, single curve, single step."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from supernnova_amd.modules import unpack_packed_sequence
+    g = torch.Generator().manual_seed(0)
+    for trial, (B, T) in enumerate([(1, 1), (1, 9), (7, 1), (33, 40), (128, 40), (5, 3), (64, 17), (31, 29)]):
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        x = torch.randn(T, B, 6, generator=g)
+        srt = trial % 2 == 0
+        if srt:
+            lens = lens.sort(descending=True).values
+        pk = pack_padded_sequence(x, lens, enforce_sorted=srt)
+        ref, ref_lens = pad_packed_sequence(pk)
+        got, got_lens = unpack_packed_sequence(pk)
+        assert torch.equal(ref, got) and got.dtype == torch.float32
+        assert got_lens.dtype == np.int32 and np.array_equal(ref_lens.numpy(), got_lens)
