@@ -106,14 +106,14 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
     return s;
 }
 
-__global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
+__global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
                                                         const float* __restrict__ rho,
                                                         const float* __restrict__ eps, int mode,
                                                         uint64_t seed, uint64_t offset, snn_prior prior,
                                                         float* __restrict__ wk, float* __restrict__ kl_terms,
                                                         int64_t mu_stride)
 {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int tau = blockIdx.x, s = blockIdx.y;
     mu += (int64_t)s * mu_stride;   // snn_prepare_weights_multi: one canonical weight set per sample
     const TensorGeom g = tensor_geom(y, tau);
@@ -403,7 +403,8 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
 {
     if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0 || y.cell != 0)  // padding words exist: define them
         HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
-    hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
+    // a training step samples ONE weight set: 22 workgroups, so make them wide (the per-tensor loop is a latency chain)
+    hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(S < 8 ? 1024 : 256), 0, st, y, mu, rho, eps, mode, seed,
                        offset, prior, wk, kl ? kl_terms : nullptr, mu_stride);
     HIP_CHECK(hipGetLastError());
     if (kl) {

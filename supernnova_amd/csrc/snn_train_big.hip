@@ -463,7 +463,7 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     // weight-gradient partial sums: one slab of P floats per chunk of tile-steps; up to 256 chunks while the slabs stay
     // under 64 MB (small models, large batches), never fewer than the 64 the large models ran with
     const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(256, ((int64_t)64 << 20) / ((int64_t)sizeof(float) * y.P)));
-    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, total / 8));
+    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, total / 2));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
 }
