@@ -77,6 +77,11 @@ def unpack_packed_sequence(x):
     bs = x.batch_sizes.numpy().astype(np.int64)
     T, B, D = bs.size, int(bs[0]), x.data.size(-1)
     total = int(bs.sum())
+    if total > 32768:
+        # large batches: torch's T copies are bandwidth-bound and cheaper than building and uploading a row map
+        # (MI355X, T = 40, D = 24: 0.19 ms vs 0.31 ms at 8192 curves; 0.19 vs 0.04 ms at 128 curves the other way)
+        padded, lens = pad_packed_sequence(x)
+        return padded.float(), lens.numpy().astype(np.int32)
     start = np.zeros(T, np.int64)
     np.cumsum(bs[:-1], out=start[1:])
     t_idx = np.repeat(np.arange(T, dtype=np.int64), bs)

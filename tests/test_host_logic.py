@@ -227,7 +227,7 @@ def test_unpack_packed_sequence_equals_pad_packed_sequence():
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from supernnova_amd.modules import unpack_packed_sequence
     g = torch.Generator().manual_seed(0)
-    for trial, (B, T) in enumerate([(1, 1), (1, 9), (7, 1), (33, 40), (128, 40), (5, 3), (64, 17), (31, 29)]):
+    for trial, (B, T) in enumerate([(1, 1), (1, 9), (7, 1), (33, 40), (128, 40), (5, 3), (64, 17), (31, 29), (2000, 40), (2001, 40)]):
         lens = torch.randint(1, T + 1, (B,), generator=g)
         x = torch.randn(T, B, 6, generator=g)
         srt = trial % 2 == 0
