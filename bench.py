@@ -271,7 +271,7 @@ def main():
         b3 = args.precision != "f32"
         npr = 6 if args.precision == "bf16x3" else 3     # piece products per fp32 product
         peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else
-                                              "lstm_fwd_kernel<32,12,2,masked>" if var else "lstm_fwd_pair_kernel<32,12,2>")
+                                              "lstm_fwd_pair_kernel<32,12,2,masked>" if var else "lstm_fwd_pair_kernel<32,12,2>")
         if b3:
             # executed 16-bit MFMA FLOPs: 6 (bf16x3) / 3 (f16x2) piece products per fp32 product, K padded to blocks of 16
             H, Dp16 = cfg.hidden_size, -(-cfg.input_size // 16) * 16

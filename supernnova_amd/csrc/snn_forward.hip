@@ -291,7 +291,7 @@ struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool 
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
-fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs);      // snn_forward_pair.hip
+fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs, bool masked);      // snn_forward_pair.hip
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
 fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs);     // snn_forward_b3p.hip (same, two tiles per workgroup)
@@ -604,10 +604,11 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
         if (!rc) rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
-        if (fwd_kernel_t fp = rc ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs)) {
-            rc = fwd_geom(y, fp, false, max_T, &gt, true);
-            if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
-        }
+        for (int m = 0; m < 2; ++m)
+            if (fwd_kernel_t fp = rc ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs, m == 1)) {
+                rc = fwd_geom(y, fp, false, max_T, &gt, true);
+                if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+            }
     }
     return rc ? rc : g.ws_bytes;
 }
@@ -679,9 +680,9 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     if (e->big && !train && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)
     bool pair = false;
-    if (!train && !masked && !e->big && n_tiles > 1 && y.cell == 0) {
+    if (!train && (!masked || masks->mid_T == 1) && !e->big && n_tiles > 1 && y.cell == 0) {   // locked masks only
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
-        fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs);
+        fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs, masked);
         if (fp) { fn = fp; pair = true; }
     }
     FwdGeom g;

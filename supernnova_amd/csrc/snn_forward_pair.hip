@@ -1,4 +1,5 @@
-// snn_forward_pair.hip -- persistent LSTM forward, two 32-curve tiles per workgroup (inference, no masks).
+// snn_forward_pair.hip -- persistent LSTM forward, two 32-curve tiles per workgroup (inference; MASKED variant for the
+// locked variational masks, applied exactly as lstm_fwd_kernel applies them: same products, same bits).
 //
 // Same decomposition as lstm_fwd_kernel (wave w owns the 4 gates of hidden units 8w..8w+7, weights of the
 // running (layer, direction) in registers, B operand = [x_t | h_{t-1}] of 32 curves from LDS), but every
@@ -26,6 +27,9 @@
 #ifndef SNN_PAIR_WAVES
 #define SNN_PAIR_WAVES 3
 #endif
+#ifndef SNN_PAIR_MASKED_WAVES
+#define SNN_PAIR_MASKED_WAVES 3   // 2 -> 3: 775 -> 744 ms per 1 M curves x 50 samples (spills and all)
+#endif
 
 struct PairCtx {
     int s, T, w, lane, cl, hf, tid;
@@ -46,7 +50,7 @@ __device__ __forceinline__ float lane_select(unsigned long long mask, float a, f
     return r;
 }
 
-template <int H, int KKI, int DIRS, bool FIRST, bool LAST>
+template <int H, int KKI, int DIRS, bool FIRST, bool LAST, bool MASKED>
 __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c, int l, int d, int k_A, int k_bias,
                                            int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
 {
@@ -66,12 +70,45 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];
     }
+    const MaskP& mk = p.mk;
+    // variational W_hh row mask: forward direction only (variational_rnn.py:45, 224-238)
+    if (MASKED && d == 0) {
+        const int r = c.lane & 31;
+        const float m = mask_whh(mk, c.s, y.L, H, l, (r >> 3) * H + 8 * c.w + (r & 7));
+#pragma unroll
+        for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
+    }
     if (c.cl < 16) {
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
         bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
     }
     const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
     const int j0 = 8 * c.w + 4 * c.hf;
+    // locked between-layer mask of this lane's 4 units, and the layer-0 input mask of the staging threads
+    float mmid[2][4], min_[2][NPT][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            mmid[q][u] = (MASKED && !last_layer && c.orig[q] >= 0)
+                             ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, c.orig[q], d * H + j0 + u) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) min_[q][i][e] = 1.0f;
+        if (MASKED && FIRST) {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int f = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
+                const int k = f >> 3, c4 = (f & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = p.order[c.tile[q] * SNN_TILE + c4 + e];
+                    if (o >= 0 && k < y.D) min_[q][i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k);
+                }
+            }
+        }
+    }
 
     const float* in0[2];
     float* yout[2];
@@ -102,7 +139,12 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
-            *reinterpret_cast<f32x4*>(xin + q * XIN + f * 4) = pre[i];
+            f32x4 v = pre[i];
+            if (MASKED && FIRST) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[q][i][e], v[e]);
+            }
+            *reinterpret_cast<f32x4*>(xin + q * XIN + f * 4) = v;
         }
     };
     // B operand k of tile q: [x_t | h_{t-1}] rows 2k, 2k+1 (lane = (row & 1) * 32 + curve)
@@ -141,7 +183,7 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
             const float outv = lane_select(vmask, hv, 0.0f);
             hb[q * HB + (j0 + u) * 32 + c.cl] = hst[q][u];
             if (last_layer) hsum[q][u] += outv;
-            else yout[q][(int64_t)t * HB + (j0 + u) * 32 + c.cl] = outv;
+            else yout[q][(int64_t)t * HB + (j0 + u) * 32 + c.cl] = MASKED ? __fmul_rn(mmid[q][u], outv) : outv;
         }
     };
     // One pipeline phase: the MFMA chain of tile qc (into accc), with the cell update of tile qa (from acca, step ta)
@@ -231,6 +273,10 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
                     fidx[u] = (j0 + u) * (y.L * DIRS) + ld;
                 }
             }
+            if (MASKED && c.orig[q] >= 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) feat[u] = __fmul_rn(mask_out(mk, c.s, p.n_curves, y.F, c.orig[q], fidx[u]), feat[u]);
+            }
             for (int cq = 0; cq < y.C; ++cq) {
                 float a = 0.0f;
 #pragma unroll
@@ -251,8 +297,8 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
     __syncthreads();  // also publishes this phase's y stores to the workgroup
 }
 
-template <int H, int KKI0, int DIRS>
-__global__ void __launch_bounds__(H * 8, SNN_PAIR_WAVES) lstm_fwd_pair_kernel(const FwdParams p)
+template <int H, int KKI0, int DIRS, bool MASKED>
+__global__ void __launch_bounds__(H * 8, MASKED ? SNN_PAIR_MASKED_WAVES : SNN_PAIR_WAVES) lstm_fwd_pair_kernel(const FwdParams p)
 {
     constexpr int NT = H * 8, NW = H / 8;
     constexpr int KKI1 = DIRS * H / 2;
@@ -308,12 +354,12 @@ __global__ void __launch_bounds__(H * 8, SNN_PAIR_WAVES) lstm_fwd_pair_kernel(co
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0, kB = kA + NW * (KKI0 + H / 2) * 64;
-                    if (last) pair_phase<H, KKI0, DIRS, true, true>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
-                    else pair_phase<H, KKI0, DIRS, true, false>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    if (last) pair_phase<H, KKI0, DIRS, true, true, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    else pair_phase<H, KKI0, DIRS, true, false, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1, kB = kA + NW * (KKI1 + H / 2) * 64;
-                    if (last) pair_phase<H, KKI1, DIRS, false, true>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
-                    else pair_phase<H, KKI1, DIRS, false, false>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    if (last) pair_phase<H, KKI1, DIRS, false, true, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    else pair_phase<H, KKI1, DIRS, false, false, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
                 }
             }
         }
@@ -343,11 +389,11 @@ __global__ void __launch_bounds__(H * 8, SNN_PAIR_WAVES) lstm_fwd_pair_kernel(co
 
 // ---- registry hook used by snn_forward.hip --------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs)
+fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs, bool masked)
 {
     if (H == 32 && dirs == 2) {
-        if (KKI0 == 12) return lstm_fwd_pair_kernel<32, 12, 2>;
-        if (KKI0 == 13) return lstm_fwd_pair_kernel<32, 13, 2>;
+        if (KKI0 == 12) return masked ? lstm_fwd_pair_kernel<32, 12, 2, true> : lstm_fwd_pair_kernel<32, 12, 2, false>;
+        if (KKI0 == 13) return masked ? lstm_fwd_pair_kernel<32, 13, 2, true> : lstm_fwd_pair_kernel<32, 13, 2, false>;
     }
     return nullptr;
 }

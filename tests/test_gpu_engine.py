@@ -446,3 +446,36 @@ def test_gru_rnn_are_inference_only():
     masks = E.Masks(mode=L.SNN_MASK_PHILOX, which=8, dropout=0.1, seed=1)
     with pytest.raises(L.SnnError, match="masked"):
         E.lstm_forward(cfg, plan, xp, wk, 1, masks=masks)
+
+
+@pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 97, 17), (26, 3, "standard", 3, 64, 9), (24, 2, "mean", 1, 40, 12)])
+def test_masked_paired_tile_kernel_matches_single_tile_kernel_and_oracle(D, C, pool, L, N, T):
+    """Locked variational masks over more than one tile run the MASKED two-tiles-per-workgroup kernel; <= 32 curves run
+    lstm_fwd_kernel<MASKED>.  Same curves, same mask values: bit-identical results through both, and both match the
+    oracle; Philox masks (keyed by curve index) give the same bits in a 32-curve and in a multi-tile launch."""
+    E = _eng()
+    H, S, p = 32, 3, 0.15
+    cfg = E.Config(D, H, L, True, C, pool)
+    ocfg = oracle.make_cfg(D, H, L, True, C, pool)
+    g = np.random.default_rng(17)
+    w = _random_model(cfg, 33, 0.15)
+    x, lengths = make_curves(34, N, T, D, min_len=1)
+    wk = E.prepare_weights(cfg, _t(w))
+    bern = lambda *s: (g.random(s) < 1 - p).astype(np.float32) / np.float32(1 - p)
+    m_in, m_whh, m_out = bern(S, N, D), bern(S, L, 4 * H), bern(S, N, cfg.F)
+    m_mid = bern(S, max(L - 1, 1), 1, N, 2 * H)
+
+    def masks(a=0, b=N):
+        return E.Masks(mode=1, m_in=_t(m_in[:, a:b]), m_whh=_t(m_whh), m_mid=_t(m_mid[:, :, :, a:b]) if L > 1 else None,
+                       m_out=_t(m_out[:, a:b]), mid_T=1)
+    lo, pr = _run(E, cfg, x, lengths, wk, S, masks())
+    for a in range(0, N, 32):
+        lo1, pr1 = _run(E, cfg, np.ascontiguousarray(x[:, a:a + 32]), lengths[a:a + 32], wk, S, masks(a, a + 32))
+        assert np.array_equal(lo1, lo[:, a:a + 32]) and np.array_equal(pr1, pr[:, a:a + 32])
+    for s in range(S):
+        o = oracle.forward(ocfg, x, lengths, w, m_in[s], m_whh[s], m_mid[s] if L > 1 else None, m_out[s])
+        _check(lo[s], pr[s], o["logits"], o["probs"])
+    ph = lambda: E.Masks(mode=2, which=15, dropout=p, seed=5, mid_T=1)
+    lo2, _ = _run(E, cfg, x, lengths, wk, S, ph())
+    lo3, _ = _run(E, cfg, np.ascontiguousarray(x[:, :32]), lengths[:32], wk, S, ph())
+    assert np.array_equal(lo3, lo2[:, :32])
