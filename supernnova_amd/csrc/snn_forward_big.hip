@@ -105,6 +105,9 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     };
 
     // ================= pass 1: Gx[t][tile][i][lane] = W_ih x_t + b ===================================
+#ifdef SNN_ABL_BIG_NOP1   // timing ablation only (results are wrong): the recurrent pass alone
+    if (p.n_curves >= 0) goto pass2;
+#endif
     for (int r0 = 0; r0 < RT; r0 += TP) {
         float wx[TP][KKI];
         f32x16 binit[TP];
@@ -133,11 +136,19 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
             for (int r = 0; r < TP; ++r) acc[r] = binit[r];
             const float* xc = xin + cur * XIN_STRIDE + c.lane;
+            // B operands are read from LDS BA k-steps ahead of their MFMAs (sched_barrier keeps the order): with one or
+            // two MFMAs per k-step the LDS latency is otherwise exposed at every k-step
+            constexpr int BA = 4;
+            float bq[BA];
+#pragma unroll
+            for (int kk = 0; kk < BA && kk < KKI; ++kk) bq[kk] = xc[kk * 64];
 #pragma unroll
             for (int kk = 0; kk < KKI; ++kk) {
-                const float b = xc[kk * 64];
+                const float b = bq[kk % BA];
+                if (kk + BA < KKI) bq[kk % BA] = xc[(kk + BA) * 64];
 #pragma unroll
                 for (int r = 0; r < TP; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[r][kk], b, acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < TP; ++r) {
@@ -149,6 +160,9 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
             lds_barrier();
         }
     }
+#ifdef SNN_ABL_BIG_NOP1
+pass2:
+#endif
     __syncthreads();  // Gx visible to the whole workgroup (each wave reads its own tiles, but keep it simple)
 
     // ================= pass 2: recurrence ==========================================================
@@ -235,7 +249,12 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
                 }
             }
             // the next step's Gx for this tile goes straight into the now-free accumulator
-            if (more) {
+#ifdef SNN_ABL_BIG_NOGX   // timing ablation only (results are wrong): no Gx reload
+            if (more && p.n_curves < 0)
+#else
+            if (more)
+#endif
+            {
                 const float* g = gx + ((int64_t)tn * NWT + (c.w * RT + r)) * 1024 + c.lane;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
@@ -344,11 +363,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 1), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
+                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 2), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
                                                                             k_head_w, xin, hb, part, logit, mlds, gx);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 1), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
+                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 2), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
                                                                              k_head_w, xin, hb, part, logit, mlds, gx);
                 }
             }
