@@ -43,16 +43,17 @@ static const BwdEntry* find_bwd(const SnnLayout& y)
     return y.H == 32 ? snn_bwd_small_h32(y.KKI[0], y.dirs) : nullptr;
 }
 // H = 32 has both paths.  Measured on MI355X (BayesianRNN train step, lengths U{3..40}), ms per step at batch
-// 128 / 2048 / 4096 / 8192 / 16384 / 32768: fused 1.44 / 1.47 / 1.56 / 1.72 / 2.64 / 4.14, split 0.73 / 0.88 / 1.10 /
-// 1.56 / 2.68 / 4.56: the split path runs both directions and the weight-gradient GEMMs in parallel (latency), the
-// fused one keeps dG on chip (throughput).  SNN_BWD_PATH=fused|split overrides (A/B measurements).
+// 128 / 8192 / 16384 / 32768 / 65536: fused 1.32 / 1.66 / 2.57 / 4.05 / 7.43, split 0.59 / 1.33 / 2.25 / 3.73 / 7.08: the
+// split path runs both directions and the weight-gradient GEMMs in parallel; the fused one keeps dG on chip and needs a
+// workspace that does not grow with the batch (the split path's dG / dy buffers take 64 KB per tile-step: 4 GB at 65536
+// curves x 40 steps), so it takes over above 8192 tiles.  SNN_BWD_PATH=fused|split overrides (A/B measurements).
 static bool use_split_path(const SnnLayout& y, const BwdEntry* fused, int n_tiles)
 {
     if (!fused) return true;
     static const char* force = getenv("SNN_BWD_PATH");
     if (force && force[0] == 'f') return false;
     if (force && force[0] == 's') return true;
-    return n_tiles <= 256;
+    return n_tiles <= 8192;
 }
 // H = 64, 128: recurrent kernel + deferred GEMMs (snn_train_big.hip)
 bool snn_bwd_big_supported(const SnnLayout& y);

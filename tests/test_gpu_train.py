@@ -309,7 +309,7 @@ def test_layerwise_training_forward_is_bit_identical_to_the_persistent_kernel(po
     from supernnova_amd import engine as E
     from util import make_curves
     cfg = E.Config(24, 32, 2, True, C, pool)
-    n_small, n_big, T = 100, 4200, 30          # 4 tiles (layer-wise path) vs 132 tiles (> half the CUs: persistent kernel)
+    n_small, n_big, T = 100, 8400, 30          # 4 tiles (layer-wise path) vs 263 tiles (tiles x 2 > 2 x 256 CUs: persistent kernel)
     x, lengths = make_curves(21, n_big, T, 24, min_len=1)
     lengths[:n_small] = np.maximum(lengths[:n_small], 2)
     w = np.random.default_rng(4).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
