@@ -680,7 +680,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     if (e->big && !train && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)
     bool pair = false;
-    if (!train && (!masked || masks->mid_T == 1) && !e->big && n_tiles > 1 && y.cell == 0) {   // locked masks only
+    if (!train && (!masked || masks->mid_T <= 1) && !e->big && n_tiles > 1 && y.cell == 0) {   // locked masks only
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
         fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs, masked);
         if (fp) { fn = fp; pair = true; }
