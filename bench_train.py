@@ -49,16 +49,24 @@ def main():
     ap.add_argument("--max-len", type=int, default=40)
     ap.add_argument("--full-length", action="store_true", help="every curve has max-len steps (configs[4]: 300)")
     args = ap.parse_args()
+    if os.environ.get("SNN_BENCH_WATCHDOG"):   # seconds; a stuck rank prints where it is and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SNN_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
+    # correctness only -- gloo stages every all-reduce of a device tensor through the host, ~1-2 s per step here)
+    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from supernnova_amd import distributed as D
     from supernnova_amd.utils import training_utils as tu
-    D.init_from_env("nccl", dev)
+    D.init_from_env(backend, dev)
 
     st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0,
                   hidden_dim=args.hidden, nb_classes=args.classes)
