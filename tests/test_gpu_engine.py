@@ -525,3 +525,35 @@ def test_full_shard_size_properties():
         w, _ = oracle.bbb_sample(mu[:cfg.P - C], rho, eps[s])
         o = oracle.forward(ocfg, x_pad, lengths[sub], np.concatenate([w, mu[cfg.P - C:]]))
         _check(lo2[s], pr2[s], o["logits"], o["probs"])
+
+
+@pytest.mark.parametrize("name,prec,D,H,C,N,T,full", [("configs[1] variational", "f32", 24, 32, 2, 1_000_000, 40, False),
+                                                      ("configs[1] variational", "f16x2", 24, 32, 2, 1_000_000, 40, False),
+                                                      ("configs[4] elasticc-like", "f32", 78, 128, 14, 8192, 300, True)])
+def test_other_configs_at_full_size(name, prec, D, H, C, N, T, full):
+    """BASELINE configs[1] (VariationalRNN, Philox masks keyed by curve index, 1 M curves) and configs[4] (H = 128, D = 78,
+    300-step sequences) at full size, S = 50: a contiguous block of curves re-run in its own launch (curve_base = first
+    index, so the mask keys agree) gives the same bits; probabilities finite and normalised."""
+    E = _eng()
+    S, var = 50, name.startswith("configs[1]")
+    cfg = E.Config(D, H, 2, True, C, "mean", precision=prec)
+    g = np.random.default_rng(99)
+    lengths = (np.full(N, T) if full else g.integers(3, T + 1, size=N)).astype(np.int32)
+    off = np.zeros(N, np.int64)
+    np.cumsum(lengths[:-1].astype(np.int64) * D, out=off[1:])
+    rows = torch.randn(int(lengths.sum()), D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    if var:
+        wk = E.prepare_weights(cfg, _t(_random_model(cfg, 5, 0.25)))
+    else:
+        wk = E.prepare_weights_multi(cfg, _t(g.uniform(-0.1, 0.1, (S, cfg.P))))
+    mk = (lambda base: E.Masks(mode=2, which=15, dropout=0.05, seed=11, mid_T=1, curve_base=base)) if var else (lambda base: None)
+    plan = E.Plan(cfg, lengths, DEV)
+    xp = E.pack_ragged(cfg, plan, rows, torch.from_numpy(off).to(DEV))
+    lo, pr = E.lstm_forward(cfg, plan, xp, wk, S, masks=mk(0))
+    assert bool(torch.isfinite(pr).all()) and float((pr.sum(-1) - 1).abs().max()) < 1e-6
+    a, n = N // 3, 80
+    r0, r1 = off[a] // D, off[a + n] // D
+    plan2 = E.Plan(cfg, lengths[a:a + n], DEV)
+    xp2 = E.pack_ragged(cfg, plan2, rows[r0:r1].contiguous(), torch.from_numpy(off[a:a + n] - off[a]).to(DEV))
+    lo2, pr2 = E.lstm_forward(cfg, plan2, xp2, wk, S, masks=mk(a))
+    assert torch.equal(lo[:, a:a + n], lo2) and torch.equal(pr[:, a:a + n], pr2)
