@@ -327,3 +327,40 @@ def test_layerwise_training_forward_is_bit_identical_to_the_persistent_kernel(po
     assert np.array_equal(out[0][0], out[1][0])
     # the gradients add the same per-curve terms in a different tile order: equal to summation rounding
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=2e-5 * np.abs(out[1][1]).max())
+
+
+@pytest.mark.parametrize("model", ["vanilla", "bayesian"])
+def test_data_parallel_gradient_equals_full_batch_gradient(model):
+    """The data-parallel step (supernnova_amd/optim.py: one sum-all-reduce of the flat gradient, scaled by 1 / world in the
+    Adam kernel) emulated in one process: the mean of the gradients of the two contiguous halves of a length-sorted
+    batch (distributed.shard_range), each with its own CE mean and the same KL term and weight draw, equals the
+    gradient of the whole batch."""
+    from test_host_logic import settings
+    from supernnova_amd import distributed as D
+    from supernnova_amd.utils import training_utils as tu
+    st = settings(model=model, dropout=0.0)
+    torch.manual_seed(3)
+    rnn = tu.get_model(st, 24).to(DEV)
+    rnn.train()
+    g = np.random.default_rng(12)
+    B, T = 96, 25
+    lengths = np.sort(g.integers(2, T + 1, size=B))[::-1].copy()
+    x = g.standard_normal((int(lengths[0]), B, 24)).astype(np.float32)
+    for b in range(B):
+        x[lengths[b]:, b] = 0
+    target = g.integers(0, 2, size=B)
+    eps = rnn.host_eps(1, DEV) if model == "bayesian" else None
+
+    class Rec:
+        def step_flat(self, grads):
+            self.g = grads.detach().clone()
+
+    def grads(s, e):
+        rec = Rec()
+        pk = pack_padded_sequence(torch.from_numpy(x[:int(lengths[s]), s:e]).to(DEV), torch.from_numpy(lengths[s:e].astype(np.int64)))
+        rnn.fused_train_step(pk, torch.from_numpy(target[s:e]).to(DEV), rec, kl_scale=1.0 / (100 * B), eps=eps)
+        return rec.g
+    full = grads(0, B)
+    parts = [grads(*D.shard_range(B, r, 2)) for r in range(2)]
+    mean = 0.5 * (parts[0] + parts[1])
+    assert float((mean - full).abs().max()) < 2e-6 * max(1.0, float(full.abs().max()))
