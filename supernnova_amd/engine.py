@@ -94,7 +94,11 @@ class Plan:
         npad = self.n_tiles * L.TILE
         # the four plan arrays are views of one host buffer, so the device copy is ONE transfer (to())
         a, b = 8 * (self.n_tiles + 1), 4 * npad
-        self._host = np.empty(a + 2 * b + 4 * self.n_tiles, np.uint8)
+        # pinned when a GPU is present: the upload is then asynchronous (a pageable source would block the host until the
+        # stream reaches the copy, i.e. serialise host and GPU once per launch)
+        self._host_t = torch.empty(a + 2 * b + 4 * self.n_tiles, dtype=torch.uint8,
+                                   pin_memory=device is not None and torch.device(device).type == "cuda")
+        self._host = self._host_t.numpy()
         self.tile_off = self._host[:a].view(np.int64)
         self.order = self._host[a:a + b].view(np.int32)
         self.len_sorted = self._host[a + b:a + 2 * b].view(np.int32)
@@ -119,7 +123,7 @@ class Plan:
 
     def to(self, device):
         self.device = torch.device(device)
-        d = torch.from_numpy(self._host).to(self.device)
+        d = self._host_t.to(self.device, non_blocking=True)
         a, b = self.tile_off.nbytes, self.order.nbytes
         self.d_tile_off = d[:a].view(torch.int64)
         self.d_order = d[a:a + b].view(torch.int32)

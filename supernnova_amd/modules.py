@@ -93,7 +93,9 @@ def unpack_packed_sequence(x):
         lens = np.empty_like(lengths)
         lens[si] = lengths
         lengths = lens
-    rows = torch.from_numpy(t_idx * B + b_idx).to(x.data.device, non_blocking=True)
+    rows_h = torch.empty(total, dtype=torch.int64, pin_memory=x.data.is_cuda)   # pinned: the upload does not block the host
+    np.add(t_idx * B, b_idx, out=rows_h.numpy())
+    rows = rows_h.to(x.data.device, non_blocking=True)
     padded = torch.zeros((T * B, D), dtype=torch.float32, device=x.data.device)
     padded.index_copy_(0, rows, x.data.float())
     return padded.view(T, B, D), lengths
@@ -151,8 +153,18 @@ class _HipRNN(nn.Module):
         raise NotImplementedError
 
     def _flat_params(self):
-        params = dict(self.named_parameters())
-        return [params[k] for _, keys in self._flat_groups() for k in keys]
+        # the Parameter objects are fixed after construction (.to() / load_state_dict re-point or fill their .data,
+        # which flat_parameters() checks); walking named_parameters() on every call cost 65 us per training step
+        cache = self.__dict__.get("_flat_params_cache")
+        if cache is None:
+            params = dict(self.named_parameters())
+            cache = [params[k] for _, keys in self._flat_groups() for k in keys]
+            self.__dict__["_flat_params_cache"] = cache
+        return cache
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_flat_params_cache", None)   # conversions may replace Parameter objects
+        return super()._apply(fn, *args, **kwargs)
 
     def _flatten(self):
         ps = self._flat_params()
