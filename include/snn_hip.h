@@ -305,7 +305,9 @@ int snn_bbb_backward(const snn_cfg *cfg, const float *mu, const float *rho, cons
 /*
  * Mean cross-entropy over n curves and dlogits = grad_scale * (softmax - onehot)  [grad_scale = 1/n
  * for the plain mean]; nn.CrossEntropyLoss at utils/training_utils.py:515 and its backward.
- * target int64 (n), loss: device scalar.
+ * target int64 (n), loss: device scalar.  The sum is taken in a fixed order (per-workgroup partials added by index by
+ * the workgroup that finishes last), so the loss does not depend on scheduling.  The partials live in one device array
+ * of the library: calls that overlap on the same GPU (different streams) race; a training step uses one stream.
  */
 int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float *logits, const int64_t *target,
                      float grad_scale, float *loss, float *dlogits, void *stream);
