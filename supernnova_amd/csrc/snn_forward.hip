@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
     float* dst = xp + tile_off[tile];
-    for (int idx = threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x) {
+    // gridDim.y > 1 for small batches (a handful of tiles is a latency chain otherwise): the tile's steps are dealt out
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x * gridDim.y) {
         const int t = idx >> 5, c = idx & 31;
         const int pos = tile * SNN_TILE + c;
         const int orig = order[pos];
@@ -391,7 +392,7 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
-    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
+    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
                        stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
