@@ -84,7 +84,7 @@ def flops_per_pass(cfg, lengths_sum, n_curves, S):
     return S * (lengths_sum * 16 * H * (D + 4 * H) + n_curves * 4 * H * C)
 
 
-def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves):
+def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves, model="bayesian"):
     x_host = np.ascontiguousarray(x_host)
     """Reference call pattern (validate_rnn.py:539-563) on the stock-PyTorch CPU port."""
     from oracle import torch_port as tp
@@ -96,8 +96,12 @@ def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves):
         I = D if l == 0 else 2 * H
         shapes += [(4 * H, I), (4 * H, H), (4 * H,), (4 * H,)] * 2
     shapes += [(C, F), (C,)]
-    mu_c, rho_c = mu.cpu(), rho.cpu()
-    for k_mu, k_rho, shp in zip(layout.bayesian_keys(2, 2, "mu"), layout.bayesian_keys(2, 2, "rho") + [None], shapes):
+    mu_c, rho_c = mu.cpu(), None if rho is None else rho.cpu()
+    if model == "variational":      # mu = the flat weight vector, no rho
+        key_pairs = [(k, None) for k in layout.variational_keys(2, 2)]
+    else:
+        key_pairs = zip(layout.bayesian_keys(2, 2, "mu"), layout.bayesian_keys(2, 2, "rho") + [None])
+    for (k_mu, k_rho), shp in zip(key_pairs, shapes):
         n = int(np.prod(shp))
         sd[k_mu] = mu_c[off:off + n].view(shp).clone()
         if k_rho is not None:
@@ -105,7 +109,7 @@ def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves):
         off += n
     curves = [x_host[:lengths_host[i], i].copy() for i in range(n_curves)]
     t0 = time.perf_counter()
-    tp.mc_predict("bayesian", sd, curves, S, batch_size=128, hidden=H)
+    tp.mc_predict(model, sd, curves, S, batch_size=128, hidden=H)
     dt = time.perf_counter() - t0
     return n_curves / dt, dt
 
@@ -179,6 +183,7 @@ def main():
         gw.manual_seed(0)
         k = 1.0 / np.sqrt(cfg.hidden_size)
         flat = ((torch.rand(cfg.P, generator=gw) * 2 - 1) * k).to(dev)
+        flat_unscaled = flat.clone()
         if args.precision == "f16x2":   # the f16x2 kernel applies the mask bits; 1/(1-p) goes into the weights (snn_hip.h)
             H, off, sc = cfg.hidden_size, 0, float(np.float32(1.0) / np.float32(0.95))
             for l in range(2):
@@ -339,9 +344,14 @@ def main():
                                 "kernel": "lstm_fwd_h2_kernel<32,2,2,false>", "kernel_ms": float(np.mean(fk)),
                                 "fp32_equivalent_tflops": fl / (float(np.mean(fk)) * 1e-3) / 1e12}
             del fxp, fwk, fprobs
-        if args.cpu_curves > 0 and world == 1 and not var:
+        if args.cpu_curves > 0 and world == 1:
             n_cpu = min(args.cpu_curves, N)
-            v, secs = cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu)
+            if big and args.cpu_curves == 3840:
+                n_cpu = 128       # one reference batch: 300 steps at H=128 x 50 forwards is already tens of seconds of CPU work
+            print(f"cpu baseline: {n_cpu} curves on {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
+            v, secs = (cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], flat_unscaled, None, S, n_cpu,
+                                    model="variational") if var else
+                       cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu))
             out["cpu_baseline"] = {"value": v, "unit": "light curves/s", "cores": torch.get_num_threads(),
                                    "kind": "port",
                                    "sample": f"first {n_cpu} curves of the same workload, batches of 128 x {S} "

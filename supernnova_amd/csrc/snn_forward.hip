@@ -17,7 +17,7 @@
 #include "snn_host.h"
 
 // ============================================================================
-// pack_x: one workgroup per tile, one thread per (t, curve), loop over features
+// pack_x: one workgroup per tile (split-precision images: a thread per 16-byte word; fp32 image: LDS transposition)
 // ============================================================================
 // precision 1: xp3[tile][t][XB][3 pieces][64 lanes][8 bf16], lane (curve = lane & 31, khalf = lane >> 5) holds features
 // 16 b + 8 khalf + e -- the B operand of v_mfma_f32_32x32x16_bf16, three times (hi, mid, lo)
@@ -64,6 +64,10 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
     }
 }
 
+// Transposition through LDS: the rows of the source are read along their feature axis (a curve's D floats are
+// contiguous, so a wave touches ~3 rows instead of 64), the tile image is written along its curve axis (32 curves
+// contiguous).  PACK_TS time steps per barrier pair; dynamic LDS = PACK_TS * Dp * 33 floats.
+#define PACK_TS 4
 __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float* __restrict__ x,
                                                     int64_t stride_t, int64_t stride_n,
                                                     const int64_t* __restrict__ curve_off,
@@ -73,19 +77,36 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
                                                     const int64_t* __restrict__ tile_off,
                                                     float* __restrict__ xp)
 {
+    extern __shared__ float pk_lds[];
+    __shared__ int64_t s_base[SNN_TILE];
+    __shared__ int s_len[SNN_TILE];
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
     float* dst = xp + tile_off[tile];
-    // gridDim.y > 1 for small batches (a handful of tiles is a latency chain otherwise): the tile's steps are dealt out
-    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < T * SNN_TILE; idx += blockDim.x * gridDim.y) {
-        const int t = idx >> 5, c = idx & 31;
-        const int pos = tile * SNN_TILE + c;
+    if (threadIdx.x < SNN_TILE) {
+        const int pos = tile * SNN_TILE + threadIdx.x;
         const int orig = order[pos];
-        const bool live = orig >= 0 && t < len_sorted[pos];
-        const int on = live ? orig : 0;
-        const float* src = x + (int64_t)t * stride_t + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
-        float* o = dst + (int64_t)t * Dp * SNN_TILE + c;
-        for (int k = 0; k < Dp; ++k) o[(int64_t)k * SNN_TILE] = (live && k < D) ? src[k] : 0.0f;
+        s_len[threadIdx.x] = orig >= 0 ? len_sorted[pos] : 0;
+        s_base[threadIdx.x] = orig >= 0 ? (curve_off ? curve_off[orig] : (int64_t)orig * stride_n) : 0;
+    }
+    __syncthreads();
+    const int row = SNN_TILE * D, img = SNN_TILE * Dp;
+    // gridDim.y > 1 for small batches (a handful of tiles is a latency chain otherwise): the tile's steps are dealt out
+    for (int t0 = blockIdx.y * PACK_TS; t0 < T; t0 += PACK_TS * gridDim.y) {
+        const int nt = min(PACK_TS, T - t0);
+        for (int e = threadIdx.x; e < nt * row; e += blockDim.x) {
+            const int tt = e / row, r = e - tt * row;
+            const int c = r / D, k = r - c * D;
+            const int t = t0 + tt;
+            pk_lds[(tt * Dp + k) * (SNN_TILE + 1) + c] = t < s_len[c] ? x[s_base[c] + (int64_t)t * stride_t + k] : 0.0f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nt * img; e += blockDim.x) {
+            const int tt = e / img, r = e - tt * img;
+            const int k = r >> 5, c = r & 31;
+            dst[(int64_t)(t0 + tt) * img + r] = k < D ? pk_lds[(tt * Dp + k) * (SNN_TILE + 1) + c] : 0.0f;
+        }
+        __syncthreads();
     }
 }
 
@@ -392,7 +413,8 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
-    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, y.D, y.Dp, x, stride_t,
+    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256),
+                       sizeof(float) * PACK_TS * y.Dp * (SNN_TILE + 1), (hipStream_t)stream, y.D, y.Dp, x, stride_t,
                        stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
