@@ -197,7 +197,9 @@ def main():
         w_var = E.prepare_weights(cfg, flat)
     torch.cuda.synchronize()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    # one event pair per timed step, read after the closing barrier: the host is then free to build the plan of step
+    # i + 1 (a few ms of host work per 1.25 M curves) while the GPU runs step i, as a serving loop would
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     kern_ms = []
 
     def step(i, timed):
@@ -210,11 +212,11 @@ def main():
             wk, kl = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i * S)
             masks = None
         if timed:
-            ev[0].record()
+            evs[i - args.warmup][0].record()
         _, probs = E.lstm_forward(cfg, plan, xp, wk, S, masks=masks, want_logits=False, want_probs=True,
                                   sample_major=False)
         if timed:
-            ev[1].record()
+            evs[i - args.warmup][1].record()
         return probs, kl
 
     def barrier():
@@ -229,10 +231,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         probs, kl = step(args.warmup + i, True)
-        ev[1].synchronize()
-        kern_ms.append(ev[0].elapsed_time(ev[1]))
     barrier()
     dt = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,23 +321,21 @@ def main():
         if world == 1 and not b3 and not big and not var and not args.no_fast_path:
             # the opt-in split-precision path on the same inputs (same parity bar): one warm-up + `steps` passes
             fcfg = cfg.with_precision("f16x2")
-            fev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            fk = []
+            fevs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps + 1)]
             for i in range(args.steps + 1):
                 if i == 1:
                     torch.cuda.synchronize()
                     ft0 = time.perf_counter()
+                fev = fevs[i]
                 fplan = E.Plan(fcfg, lengths_host, dev)
                 fxp = E.pack_x(fcfg, fplan, x)
                 fwk, fkl = E.bbb_sample(fcfg, mu, rho, S, prior, seed=1234, offset=i * S)
                 fev[0].record()
                 _, fprobs = E.lstm_forward(fcfg, fplan, fxp, fwk, S, want_logits=False, want_probs=True, sample_major=False)
                 fev[1].record()
-                fev[1].synchronize()
-                if i >= 1:
-                    fk.append(fev[0].elapsed_time(fev[1]))
             torch.cuda.synchronize()
             fdt = time.perf_counter() - ft0
+            fk = [a.elapsed_time(b) for a, b in fevs[1:]]
             assert bool(torch.isfinite(fprobs).all())
             out["fast_path"] = {"precision": "f16x2 (each fp32 product = 3 fp16 piece products, fp32 accumulate; "
                                              "opt-in, same 1e-5 parity bar)",

@@ -557,3 +557,34 @@ def test_other_configs_at_full_size(name, prec, D, H, C, N, T, full):
     xp2 = E.pack_ragged(cfg, plan2, rows[r0:r1].contiguous(), torch.from_numpy(off[a:a + n] - off[a]).to(DEV))
     lo2, pr2 = E.lstm_forward(cfg, plan2, xp2, wk, S, masks=mk(a))
     assert torch.equal(lo[:, a:a + n], lo2) and torch.equal(pr[:, a:a + n], pr2)
+
+
+@pytest.mark.parametrize("D,H,N,T", [(24, 32, 70, 40), (23, 32, 1, 1), (78, 128, 45, 19), (26, 64, 9000, 13)])
+def test_pack_image_is_the_documented_layout(D, H, N, T):
+    """snn_pack_x (fp32 image), padded and ragged sources: xp[tile_off[tile] + (t*Dp + k)*32 + c] = x[t, order[tile*32+c], k]
+    for t < length, 0 in the padding (k >= D, t >= length, missing curves) -- bit for bit, for a handful of tiles
+    (steps dealt over 8 workgroups per tile) and for more than 256 tiles (one workgroup per tile)."""
+    E = _eng()
+    cfg = E.Config(D, H, 2, True, 2, "mean")
+    x, lengths = make_curves(21, N, T, D, min_len=1)
+    x = x + (np.arange(T)[:, None, None] >= lengths[None, :, None]) * 7.0     # junk in the padding must not leak
+    x = x.astype(np.float32)
+    plan = E.Plan(cfg, lengths, "cuda:0")
+    Dp = cfg.x_step_floats // 32
+    assert Dp >= D
+    want = np.zeros(plan.packed_floats(cfg), np.float32)
+    for tile in range(plan.n_tiles):
+        Tt = int(plan.tile_T[tile])
+        img = want[plan.tile_off[tile]:plan.tile_off[tile] + Tt * Dp * 32].reshape(Tt, Dp, 32)
+        for c in range(32):
+            o = int(plan.order[tile * 32 + c])
+            if o >= 0:
+                img[:lengths[o], :D, c] = x[:lengths[o], o, :]
+    got = E.pack_x(cfg, plan, _t(x)).cpu().numpy()
+    assert np.array_equal(got, want)
+    got_bt = E.pack_x(cfg, plan, _t(np.ascontiguousarray(x.transpose(1, 0, 2))), time_major=False).cpu().numpy()
+    assert np.array_equal(got_bt, want)
+    rows = np.concatenate([x[:lengths[i], i] for i in range(N)])
+    off = np.concatenate([[0], np.cumsum(lengths.astype(np.int64))[:-1]]) * D
+    got_r = E.pack_ragged(cfg, plan, _t(rows), torch.from_numpy(off.astype(np.int64)).to("cuda:0")).cpu().numpy()
+    assert np.array_equal(got_r, want)
