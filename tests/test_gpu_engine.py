@@ -588,3 +588,43 @@ def test_pack_image_is_the_documented_layout(D, H, N, T):
     off = np.concatenate([[0], np.cumsum(lengths.astype(np.int64))[:-1]]) * D
     got_r = E.pack_ragged(cfg, plan, _t(rows), torch.from_numpy(off.astype(np.int64)).to("cuda:0")).cpu().numpy()
     assert np.array_equal(got_r, want)
+
+
+@pytest.mark.parametrize("prec", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("D,N,T", [(24, 70, 40), (23, 1, 1), (42, 300, 9)])
+def test_split_precision_pack_image_is_the_documented_layout(prec, D, N, T):
+    """snn_pack_x, split-precision images (include/snn_hip.h): per (tile, t) XB blocks of NPC pieces of 64 lanes x 8
+    16-bit values; lane (curve = lane & 31, khalf = lane >> 5) holds features 16 b + 8 khalf + e.  f16x2 pieces:
+    hi = fp16(x), lo = fp16((x - hi) * 2048); bf16x3: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) --
+    round-to-nearest-even, bit for bit; zeros in every padding position."""
+    E = _eng()
+    cfg = E.Config(D, 32, 2, True, 2, "mean").with_precision(prec)
+    x, lengths = make_curves(22, N, T, D, min_len=1)
+    plan = E.Plan(cfg, lengths, "cuda:0")
+    npc, dt = (2, torch.float16) if prec == "f16x2" else (3, torch.bfloat16)
+    XB = cfg.x_step_floats * 2 // (npc * 64 * 8)
+    assert XB * 16 >= D
+    xt = torch.from_numpy(x)
+    hi = xt.to(dt)
+    if prec == "f16x2":
+        pieces = [hi, ((xt - hi.float()) * 2048.0).to(dt)]
+    else:
+        r1 = xt - hi.float()
+        mid = r1.to(dt)
+        pieces = [hi, mid, (r1 - mid.float()).to(dt)]
+    pieces = [p.view(torch.int16).numpy() for p in pieces]
+    fp32_cfg = cfg.with_precision("f32")
+    step_off = (plan.tile_off // (fp32_cfg.x_step_floats)).astype(np.int64)     # first (tile, t) step of each tile
+    want = np.zeros((plan.total_steps, XB, npc, 64, 8), np.int16)
+    for tile in range(plan.n_tiles):
+        for c in range(32):
+            o = int(plan.order[tile * 32 + c])
+            if o < 0:
+                continue
+            n = int(lengths[o])
+            for k in range(D):
+                b, kh, e = k // 16, (k % 16) // 8, k % 8
+                for p in range(npc):
+                    want[step_off[tile]:step_off[tile] + n, b, p, c + 32 * kh, e] = pieces[p][:n, o, k]
+    got = E.pack_x(cfg, plan, _t(x)).view(torch.int16).cpu().numpy().reshape(want.shape)
+    assert np.array_equal(got, want)
