@@ -58,7 +58,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
-    # correctness only -- gloo stages every all-reduce of a device tensor through the host, ~1-2 s per step here)
+    # correctness only -- the gradient all-reduce is staged through the host, see distributed.allreduce_mean_scale)
     backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
@@ -109,7 +109,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(loss))

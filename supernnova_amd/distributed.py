@@ -48,7 +48,14 @@ def allreduce_mean_scale(flat, group=None):
     """Sum-all-reduce `flat` in place (one call) and return the factor that turns the sum into the mean."""
     w = world_size(group)
     if w > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal only (ranks sharing a GPU): gloo's own device-tensor path stalled here with two processes on
+            # one card, so the buffer is staged through the host explicitly; RCCL ("nccl") reduces in place
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / w
 
 
