@@ -138,11 +138,15 @@ def main():
                          "bf16 / three fp16 piece products on the 16-bit matrix pipe (include/snn_hip.h)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU BEFORE anything here touches the GPU
+        from supernnova_amd.distributed import self_launch
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -199,8 +203,9 @@ def main():
 
     # one event pair per timed step, read after the closing barrier: the host is then free to build the plan of step
     # i + 1 (a few ms of host work per 1.25 M curves) while the GPU runs step i, as a serving loop would
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     kern_ms = []
+    from supernnova_amd import distributed as Dist
 
     def step(i, timed):
         plan = E.Plan(cfg, lengths_host, dev)
@@ -217,7 +222,13 @@ def main():
                                   sample_major=False)
         if timed:
             evs[i - args.warmup][1].record()
-        return probs, kl
+        # the only exchange of the inference path: per-curve mean / std over the S draws, (N_local, 2C),
+        # reduced on the device and gathered to rank 0 -- inside the timed region
+        std, mean = torch.std_mean(probs, dim=1, unbiased=True)
+        gathered = Dist.gather_predictions(torch.cat([mean, std], dim=1), world * N)
+        if timed:
+            evs[i - args.warmup][2].record()
+        return probs, kl, gathered
 
     def barrier():
         torch.cuda.synchronize()
@@ -230,10 +241,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        probs, kl = step(args.warmup + i, True)
+        probs, kl, gathered = step(args.warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    kern_ms = [a.elapsed_time(b) for a, b, _ in evs]
+    gather_ms = [b.elapsed_time(c) for _, b, c in evs]
+    if rank == 0:
+        assert tuple(gathered.shape) == (world * N, 2 * cfg.nb_classes) and bool(torch.isfinite(gathered).all())
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,6 +325,10 @@ def main():
                                     f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
                        "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
+            "gather": {"what": "per-curve mean and std over the S draws, (N_local, 2C) fp32, reduced on the device and "
+                               "gathered to rank 0 (the path's only exchange; inside the timed region)",
+                       "bytes_per_rank": N * 2 * cfg.nb_classes * 4, "ms_per_step": float(np.mean(gather_ms)),
+                       "backend": (backend if world > 1 else None)},
             "roofline": {"bound": "mfma",
                          "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,

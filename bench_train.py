@@ -49,9 +49,24 @@ def main():
     ap.add_argument("--max-len", type=int, default=40)
     ap.add_argument("--full-length", action="store_true", help="every curve has max-len steps (configs[4]: 300)")
     args = ap.parse_args()
-    if os.environ.get("SNN_BENCH_WATCHDOG"):   # seconds; a stuck rank prints where it is and exits
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["SNN_BENCH_WATCHDOG"]), exit=True)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench_train.py --gpus N`: one fresh process per GPU, started before anything touches the GPU
+        from supernnova_amd.distributed import self_launch
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    # SNN_BENCH_WATCHDOG=<seconds>: INACTIVITY limit, re-armed after init and after every step, so a stuck rank prints
+    # where it is and exits while slow progress does not trip it; SNN_BENCH_TRACE=1 prints a time stamp per step
+    wd = int(os.environ.get("SNN_BENCH_WATCHDOG", "0"))
+    trace = bool(os.environ.get("SNN_BENCH_TRACE"))
+    import faulthandler
+
+    def alive(what):
+        if wd:
+            faulthandler.dump_traceback_later(wd, exit=True)
+        if trace:
+            print(f"[r{os.environ.get('RANK', '0')} {time.strftime('%H:%M:%S')} +{time.perf_counter() - t_start:7.3f}s] {what}",
+                  file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
+    alive("start")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,6 +82,7 @@ def main():
     from supernnova_amd import distributed as D
     from supernnova_amd.utils import training_utils as tu
     D.init_from_env(backend, dev)
+    alive("process group up")
 
     st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0,
                   hidden_dim=args.hidden, nb_classes=args.classes)
@@ -100,19 +116,37 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         loss = step()
+        alive(f"warm-up step {i} enqueued")
     barrier()
+    alive("warm-up done")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         loss = step()
+        alive(f"step {i} enqueued")
     barrier()
     dt = time.perf_counter() - t0
+    alive("timed steps done")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(loss))
+    # phase times of the fused step (HIP events on the launch stream between the C-ABI calls), a few extra steps
+    phases = None
+    if args.path == "fused":
+        acc = {}
+        n_ph = 5
+        for _ in range(n_ph):
+            rnn._timeline = []
+            step()
+            torch.cuda.synchronize()
+            tl = rnn._timeline
+            for (_, a), (name, b) in zip(tl[:-1], tl[1:]):
+                acc[name] = acc.get(name, 0.0) + a.elapsed_time(b) / n_ph
+        rnn._timeline = None
+        phases = acc
     if rank == 0:
         out = {"metric": f"light curves/s trained, {args.model} RNN (fwd + ELBO/KL bwd + Adam), data-parallel",
                "value": gB * args.steps / dt, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
@@ -121,6 +155,22 @@ def main():
                "config": {"workload": f"{args.model} LSTM {args.hidden}x2 bidirectional D={Dw} C={args.classes}, batch {B} per GPU, "
                                       + (f"{T}-step sequences, " if args.full_length else f"lengths U{{3..{T}}}, ") +
                                       f"path={args.path}", "global_batch": gB, "parallelism": f"dp{world}"}}
+        # algorithmic FLOPs: 3 x F_fwd per curve per step, F_fwd = l * 16H(D+4H) + 4HC (L=2, bidirectional)
+        H, C = args.hidden, args.classes
+        f_fwd = float(lengths.astype(np.int64).sum()) * 16 * H * (Dw + 4 * H) + B * 4 * H * C
+        PEAK = 157.3      # fp32 MFMA TFLOP/s (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
+        if phases is not None:
+            gpu_ms = sum(phases.values())
+            ach = 3 * f_fwd / (gpu_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "whole fused step (phases below; per-kernel times: profiles/r2/)",
+                "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK, "traffic": None,
+                "flop_per_step": 3 * f_fwd, "gpu_ms_per_step": gpu_ms,
+                "phases_ms": phases,
+                "forward": {"flop": f_fwd, "ms": phases.get("forward"),
+                            "frac": f_fwd / (phases["forward"] * 1e-3) / 1e12 / PEAK},
+                "backward": {"flop": 2 * f_fwd, "ms": phases.get("backward"),
+                             "frac": 2 * f_fwd / (phases["backward"] * 1e-3) / 1e12 / PEAK}}
         if args.cpu_steps > 0 and world == 1:
             from oracle import torch_port as tp
             sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in rnn.state_dict().items()}

@@ -29,6 +29,56 @@ def init_from_env(backend=None, device=None):
     return rank, world
 
 
+def self_launch(script, argv, n_ranks, timeout=None):
+    """Run `script argv` as n_ranks child processes, one per GPU, with torchrun's environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), and return the worst exit code.  The parent must not have
+    touched the GPU (it only counts devices, which does not initialise HIP); children inherit stdout / stderr, so
+    rank 0's JSON line is the parent's output.  With fewer GPUs than ranks the children would collide on RCCL
+    (one communicator rank per device), so that case needs SNN_BENCH_BACKEND=gloo (rehearsal: ranks share devices)."""
+    import socket
+    import subprocess
+    import sys
+    n_dev = torch.cuda.device_count()
+    if n_dev < n_ranks and os.environ.get("SNN_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"{os.path.basename(script)}: --gpus {n_ranks} but {n_dev} GPU(s) visible; for a rehearsal with ranks "
+              "sharing a GPU set SNN_BENCH_BACKEND=gloo", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", script, *argv], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        import time
+        t0 = time.monotonic()
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    if code != 0:
+                        rc = rc or code
+            if rc or (timeout is not None and time.monotonic() - t0 > timeout):
+                rc = rc or 124
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:          # a failed or timed-out rank: stop exactly the children started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -44,13 +94,25 @@ def shard_range(n, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
-def allreduce_mean_scale(flat, group=None):
-    """Sum-all-reduce `flat` in place (one call) and return the factor that turns the sum into the mean."""
+def allreduce_mean_scale(flat, group=None, producer_stream=None):
+    """Sum-all-reduce `flat` in place (one call) and return the factor that turns the sum into the mean.
+
+    Ordering: the kernels of this package are launched on torch's CURRENT stream (engine._stream), and
+    torch.distributed's all_reduce orders itself against the current stream on both sides (RCCL: its internal stream
+    waits on an event recorded on the current stream, and the current stream waits on the collective's end event
+    before the call returns).  So a gradient produced by the preceding launches is complete when the collective reads
+    it, and the Adam launch that follows sees the reduced values -- provided producer and consumer ARE the current
+    stream.  `producer_stream` makes that explicit for a caller that produced `flat` elsewhere: the current stream
+    waits on it first."""
     w = world_size(group)
     if w > 1:
-        if flat.is_cuda and dist.get_backend(group) == "gloo":
-            # rehearsal only (ranks sharing a GPU): gloo's own device-tensor path stalled here with two processes on
-            # one card, so the buffer is staged through the host explicitly; RCCL ("nccl") reduces in place
+        if flat.is_cuda and producer_stream is not None and producer_stream != torch.cuda.current_stream(flat.device):
+            torch.cuda.current_stream(flat.device).wait_stream(producer_stream)
+        if flat.is_cuda and dist.get_backend(group) == "gloo" and not os.environ.get("SNN_DP_GLOO_DEVICE"):
+            # gloo (CPU rehearsal of the multi-rank path with ranks sharing a GPU) has no device data path of its own:
+            # ProcessGroupGloo stages device tensors through pinned host buffers it allocates PER CALL.  Staging the
+            # 320 KB buffer ourselves is the same data movement without that per-call allocation (DESIGN.md 5 has the
+            # measurement).  .cpu() synchronises with the current stream, copy_ is enqueued on it.
             h = flat.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
             flat.copy_(h)
@@ -72,11 +134,19 @@ def gather_predictions(local, n_total, dst=0, group=None):
         return local
     sizes = [shard_range(n_total, k, w) for k in range(w)]
     nmax = max(e - s for s, e in sizes)
-    pad = local.new_zeros((nmax,) + tuple(local.shape[1:]))
-    pad[: local.shape[0]] = local
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()      # gloo has no device-tensor gather (rehearsal with ranks sharing a GPU)
+    if local.shape[0] == nmax:
+        pad = local.contiguous()
+    else:
+        pad = local.new_zeros((nmax,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
     if r == dst:
-        bufs = [torch.empty_like(pad) for _ in range(w)]
-        dist.gather(pad, bufs, dst=dst, group=group)
-        return torch.cat([b[: e - s] for b, (s, e) in zip(bufs, sizes)], dim=0)
+        out = local.new_empty((w, nmax) + tuple(local.shape[1:]))
+        dist.gather(pad, list(out.unbind(0)), dst=dst, group=group)
+        if all(e - s == nmax for s, e in sizes):
+            return out.view((w * nmax,) + tuple(local.shape[1:])).to(dev)
+        return torch.cat([out[k, : e - s] for k, (s, e) in enumerate(sizes)], dim=0).to(dev)
     dist.gather(pad, None, dst=dst, group=group)
     return None

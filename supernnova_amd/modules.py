@@ -255,8 +255,17 @@ class _HipRNN(nn.Module):
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
         cfg, dev = self.cfg, padded.device
         self.flat_parameters()
+        tl = self.__dict__.get("_timeline")      # measurement hook (bench_train.py): [(phase name, event)] per step
+
+        def mark(name):
+            if tl is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                tl.append((name, ev))
+        mark("start")
         plan = E.Plan(cfg, lengths, dev)
         xp = E.pack_x(cfg, plan, padded)
+        mark("plan+pack")
         bayes = isinstance(self, BayesianRNN)
         if masks is None and not bayes:
             masks = self._masks(plan) if isinstance(self, VanillaRNN) else \
@@ -271,9 +280,13 @@ class _HipRNN(nn.Module):
             wk, kl, terms, mode = E.bbb_sample_train(cfg, mu, rho, self._prior, eps=eps, seed=seed)
         else:
             wk = E.prepare_weights(cfg, self._flat("w"))
+        mark("sample")
         logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, masks)
+        mark("forward")
         ce, dlogits = E.ce_loss_grad(logits, target)
+        mark("ce")
         dw = E.lstm_backward(cfg, plan, xp, wk, tape, dlogits, masks)
+        mark("backward")
         if bayes:
             P, Ps = cfg.P, cfg.P - cfg.nb_classes
             gflat = torch.empty(P + Ps, dtype=torch.float32, device=dev)
@@ -283,7 +296,9 @@ class _HipRNN(nn.Module):
             loss = ce + kl * kl_scale
         else:
             gflat, loss = dw, ce
+        mark("bbb_backward")
         optimizer.step_flat(gflat)
+        mark("allreduce+adam")
         self.last_logits = logits
         return loss
 
