@@ -5,7 +5,9 @@
   eval_step        :528-544
   get_evaluation_metrics :609-707, get_loss_string :710-736, save_training_results :739-769, StopOnPlateau :847-911
   unnormalize_arr  :89-124    (needed by the 'sin' OOD transform)
-Data loading (HDF5) and plotting stay out of scope.
+  normalize_arr    :23-86, fill_data_list :127-191, load_HDF5 :194-317 (vectorised, file access through
+                   utils/data_utils.open_database)
+Plotting stays out of scope.
 """
 import json
 import os
@@ -96,6 +98,119 @@ def _ood(X, kind, settings):
         X[:, settings.idx_flux] = np.random.uniform(flux.min(), flux.max(), size=flux.shape)
         X[:, settings.idx_fluxerr] = np.random.uniform(err.min(), err.max(), size=err.shape)
     return X
+
+
+def normalize_arr(arr, settings):
+    """Clip + log-standardise the normalised columns in place (training_utils.py:23-86): float64 arithmetic on the
+    float32 values, stored back as float32.  norm "none" | "global" | "perfilter" (same formula, different arr_norm)
+    | "cosmo" | "cosmo_quantile" (per-light-curve flux scale)."""
+    if settings.norm == "none":
+        return arr
+    lo, mean, std = settings.arr_norm[:, 0], settings.arr_norm[:, 1], settings.arr_norm[:, 2]
+    cols = settings.idx_features_to_normalize
+    a = np.clip(arr[:, cols], lo, np.inf)
+    if "cosmo" not in settings.norm:
+        a = (np.log(a - lo + 1e-5) - mean) / std
+    else:
+        scale = a[:, :-1].max() if settings.norm == "cosmo" else np.quantile(a[:, :-1], 0.99)
+        a[:, :-1] = a[:, :-1] / scale
+        a[:, -1] = (np.log(a[:, -1] - lo[-1] + 1e-5) - mean[-1]) / std[-1]
+    arr[:, cols] = a
+    return arr
+
+
+class RaggedList(list):
+    """list_data as the reference's load_HDF5 returns it -- tuples (X_normed, target, SNID[, X_all, X_ori]) -- whose
+    X_normed entries are VIEWS of one concatenated (sum(len), D) float32 array: `.rows`, `.lengths`, `.curve_off`
+    (float offsets) feed snn_pack_x's ragged form directly (validate_rnn.ragged_to_device), no per-curve copy."""
+    rows = None
+    lengths = None
+    curve_off = None
+
+
+def fill_data_list(idxs, arr_data, arr_target, arr_SNID, settings, n_features, desc="", test=False):
+    """The data tuples of training_utils.py:127-191 for the light curves `idxs`, built for all curves at once: one
+    concatenated (rows, n_features) array is clipped, checked (normalise -> unnormalise round trip within 0.1, :168-172)
+    and normalised in one pass instead of a Python loop over light curves; element-wise arithmetic is the
+    reference's (float64 on float32 values, stored as float32), so every tuple equals the reference's bit for bit.
+    arr_data[i]: flat float32 array of light curve i (rows x n_features)."""
+    idxs = np.asarray(idxs, dtype=np.int64)
+    out = RaggedList()
+    if idxs.size == 0:
+        return out
+    n_features = int(n_features)
+    flat = [np.asarray(arr_data[i], dtype=np.float32) for i in idxs]
+    lengths = np.array([a.size // n_features for a in flat], np.int64)
+    X_all = np.concatenate(flat).reshape(-1, n_features)
+    cols, feat = settings.idx_features_to_normalize, settings.idx_features
+    X_ori = X_all[:, feat].copy()
+    X_all[:, cols] = np.clip(X_all[:, cols], settings.arr_norm[:, 0], np.inf)
+    bounds = np.concatenate([[0], np.cumsum(lengths)])
+    if "cosmo" in settings.norm:          # per-light-curve flux scale: curve by curve
+        X_normed = X_all.copy()
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            X_normed[a:b] = normalize_arr(X_normed[a:b].copy(), settings)
+    else:
+        X_normed = normalize_arr(X_all.copy(), settings)
+        back = unnormalize_arr(X_normed.copy(), settings)
+        if not np.all(np.isclose(np.ravel(X_all), np.ravel(back), atol=1e-1)):
+            raise AssertionError("normalisation does not round-trip within 0.1 (training_utils.py:168-172)")
+    X_normed = np.ascontiguousarray(X_normed[:, feat])
+    for k, i in enumerate(idxs):
+        a, b = bounds[k], bounds[k + 1]
+        tup = (X_normed[a:b], int(arr_target[i]), str(arr_SNID[i]))
+        out.append(tup + (X_all[a:b], X_ori[a:b]) if test else tup)
+    out.rows, out.lengths = X_normed, lengths.astype(np.int32)
+    out.curve_off = bounds[:-1] * X_normed.shape[1]
+    return out
+
+
+def load_HDF5(settings, test=False):
+    """Load `settings.processed_dir/database.h5` (training_utils.py:194-317): the test list, or (train list, val
+    list) with the reference's shuffles of numpy's global RNG and `data_fraction` cut.  The file is opened through
+    data_utils.open_database (h5py when installed, the package's native reader otherwise)."""
+    from . import data_utils as du
+    with du.open_database(f"{settings.processed_dir}/database.h5") as hf:
+        config_name = f"{settings.source_data}_{settings.nb_classes}classes"
+        split_key, target_key = f"dataset_{config_name}", f"target_{settings.nb_classes}classes"
+        if test:
+            try:        # "failsafe in case we have different classes in dataset/model" (:218-223)
+                idxs_test = np.where(hf[split_key][:] == 2)[0]
+            except Exception:
+                idxs_test = np.where(hf["dataset_photometry_2classes"][:] != 100)[0]
+        else:
+            split = hf[split_key][:]
+            idxs_train, idxs_val, idxs_test = (np.where(split == k)[0] for k in (0, 1, 2))
+            np.random.shuffle(idxs_train)
+            np.random.shuffle(idxs_val)
+            np.random.shuffle(idxs_test)
+            idxs_train = idxs_train[: int(settings.data_fraction * len(idxs_train))]
+        n_features = int(hf["data"].attrs["n_features"])
+        feats_db = list(du._as_str(hf["features"][:]))
+        feats = settings.training_features
+        if not set(feats) <= set(feats_db) and any("DES-" in k for k in feats_db):
+            feats_db = [k.replace("DES-", "") for k in feats_db]
+        assert set(feats) <= set(feats_db)
+        if not set(settings.training_features_to_normalize) <= set(feats):
+            raise ValueError("Database does not contain all training features (check --list_filters): "
+                             f"database {feats_db}, to normalize {settings.training_features_to_normalize}")
+        try:
+            settings.data_types_training = du._as_str(hf["data_types_training"][:])
+        except Exception:
+            pass
+        arr_data = hf["data"][:]
+        if test:
+            try:
+                arr_target = hf[target_key][:]
+            except Exception:
+                arr_target = hf["target_2classes"][:]
+        else:
+            arr_target = hf[target_key][:]
+        arr_SNID = du._as_str(hf["SNID"][:])
+        if test:
+            return fill_data_list(idxs_test, arr_data, arr_target, arr_SNID, settings, n_features, test=True)
+        return (fill_data_list(idxs_train, arr_data, arr_target, arr_SNID, settings, n_features),
+                fill_data_list(idxs_val, arr_data, arr_target, arr_SNID, settings, n_features))
 
 
 def get_data_batch(list_data, idxs, settings, max_lengths=None, OOD=None):

@@ -469,6 +469,261 @@ def g5_mc_stats():
              n_ref=np.int64(n_ref), S=np.int64(S), dropout=np.float32(st.dropout))
 
 
+# ---------------------------------------------------------------- G5b the sampled-mode gate as SURVEY 8d writes it
+GATE_N, GATE_G, GATE_T, GATE_SEED = 10000, 5, 40, 521
+
+
+def g5_gate(model):
+    """10 000 curves, S = 50, in mini-batches of 5 curves (one weight draw / W_hh row mask is shared by a mini-batch,
+    bayesian_rnn.py:492-496, variational_rnn.py:224-238, so curves of different batches are independent -- what the KS
+    test on the standardised differences needs).  The reference runs 100 forwards per batch; run A = draws 0..49,
+    run B = draws 50..99: per-curve mean / std (ddof 1) of both are stored, so the gate can also be evaluated
+    reference-against-reference.  Inputs are regenerated in the test from the seed (tests/util.make_curves)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_curves
+    D, S = 24, 50
+    st = settings()
+    torch.manual_seed(51)
+    cls = dict(bayesian=bayesian_rnn.BayesianRNN, variational=variational_rnn.VariationalRNN)[model]
+    m = build(cls, D, st)
+    if model == "bayesian":
+        with torch.no_grad():      # widen the posterior so the predictive std is well resolved (as g5_mcstats)
+            for n, p in m.named_parameters():
+                if "mu" in n:
+                    p.mul_(6.0)
+    m.eval()
+    x, lengths = make_curves(GATE_SEED, GATE_N, GATE_T, D)
+    mean = np.zeros((2, GATE_N, 2))
+    std = np.zeros((2, GATE_N, 2))
+    import time
+    t0 = time.time()
+    # resumable (an hour of CPU work): partial results in /tmp, each batch seeded by its own index
+    ck = f"/tmp/g5_gate_{model}.npz"
+    start = 0
+    if os.path.exists(ck):
+        z = np.load(ck)
+        mean, std, start = z["mean"], z["std"], int(z["done"])
+        print(f"  resuming {model} at curve {start}")
+    with torch.no_grad():
+        for b0 in range(start, GATE_N, GATE_G):
+            if b0 % 250 == 0 and b0 > start:
+                np.savez(ck, mean=mean, std=std, done=b0)
+            torch.manual_seed(5001 + b0)
+            idx = np.arange(b0, b0 + GATE_G)
+            srt = idx[np.argsort(-lengths[idx], kind="stable")]
+            lb = lengths[srt].astype(np.int64)
+            packed = pack_padded_sequence(torch.from_numpy(x[: lb[0], srt]), torch.from_numpy(lb))
+            pr = np.stack([softmax(m(packed)) for _ in range(2 * S)]).astype(np.float64)     # (100, G, 2)
+            for r in range(2):
+                mean[r, srt] = pr[r * S:(r + 1) * S].mean(0)
+                std[r, srt] = pr[r * S:(r + 1) * S].std(0, ddof=1)
+            if b0 % 500 == 0:
+                print(f"  g5 gate {model}: {b0} curves, {time.time() - t0:.0f} s", flush=True)
+    save(f"g5_gate_{model}", sd=sd_np(m), mean=mean.astype(np.float32), std=std.astype(np.float32),
+         n=np.int64(GATE_N), group=np.int64(GATE_G), T=np.int64(GATE_T), seed=np.int64(GATE_SEED), S=np.int64(S),
+         dropout=np.float32(st.dropout))
+
+
+# ---------------------------------------------------------------- G10 get_evaluation_metrics / get_predictions
+def _grab_nested(path, outer, inner, ns):
+    """exec the function `inner` defined INSIDE the reference function `outer` at module level of `ns`: its free
+    variables (the closure of the outer function) are then looked up in `ns`."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == outer:
+            for sub in ast.walk(node):
+                if isinstance(sub, ast.FunctionDef) and sub.name == inner:
+                    exec(compile(ast.Module([sub], []), path, "exec"), ns)
+                    return
+    raise KeyError(inner)
+
+
+def g10_settings(model, feats, arr_norm):
+    """The attributes get_data_batch / get_evaluation_metrics / _populate_predict_dict read from ExperimentSettings
+    (utils/experiment_settings.py:200-246), for 4 filters, redshift none, global normalisation."""
+    st = settings(model=model, nb_classes=2, batch_size=16, num_inference_samples=4, random_length=False,
+                  random_redshift=False, redshift="none", norm="global",
+                  pytorch_model_name=f"{model}_S_0_CLF_2", swag_scale=0.5, swag_no_lr_cov=False)
+    st.training_features = list(feats)
+    st.all_features = list(feats)
+    st.idx_flux = [i for i, f in enumerate(feats) if "FLUXCAL_" in f]
+    st.idx_fluxerr = [i for i, f in enumerate(feats) if "FLUXCALERR_" in f]
+    st.idx_delta_time = [i for i, f in enumerate(feats) if "delta_time" in f]
+    st.idx_features_to_normalize = st.idx_flux + st.idx_fluxerr + st.idx_delta_time
+    st.d_feat_to_idx = {f: i for i, f in enumerate(feats)}
+    st.arr_norm = arr_norm
+    return st
+
+
+def g10_data(n, seed, feats, arr_norm):
+    """Synthetic test list in load_HDF5's tuple form (X_normed, target, SNID, X_all, X_ori): raw delta times (first 0,
+    then 0.4..6 days), log-normal fluxes / errors, one filter-combination one-hot per step; X_normed is
+    normalize_arr's formula on the 9 normalised columns."""
+    g = np.random.default_rng(seed)
+    F = 4
+    data, peak = [], {}
+    for i in range(n):
+        L = int(g.integers(4, 31))
+        X = np.zeros((L, len(feats)), np.float32)
+        X[:, :F] = g.lognormal(3.0, 1.0, (L, F)) - 5.0
+        X[:, F:2 * F] = g.lognormal(1.0, 0.5, (L, F))
+        dt = g.uniform(0.4, 6.0, L)
+        dt[0] = 0.0
+        X[:, 2 * F] = dt
+        X[np.arange(L), 2 * F + 1 + g.integers(0, 15, L)] = 1.0
+        Xn = X.copy()
+        cols = list(range(2 * F + 1))
+        clipped = np.clip(X[:, cols], arr_norm[:, 0], np.inf)
+        Xn[:, cols] = ((np.log(clipped - arr_norm[:, 0] + 1e-5) - arr_norm[:, 1]) / arr_norm[:, 2]).astype(np.float32)
+        snid = f"{1000 + i}"
+        data.append((Xn, int(g.integers(0, 2)), snid, X, X.copy()))
+        t_end = float(np.cumsum(dt)[-1])
+        # peak inside the curve, before its first step (every early slice empty) or far after it
+        peak[snid] = [g.uniform(0, t_end), -40.0, t_end + 50.0][int(g.choice([0, 0, 0, 1, 2]))]
+    return data, peak
+
+
+def g10_predictions():
+    """a10 / a12 / f2: the reference's own get_data_batch, eval_step, get_evaluation_metrics
+    (utils/training_utils.py:374-481, 528-544, 609-707) and find_idx, construct_predict_dict, get_batch_predictions{,_MFE},
+    dispatch_batch_predictions, flatten_to_dataframe, get_aggregated_dataframe and the nested _populate_predict_dict of
+    get_predictions (validation/validate_rnn.py:19-40, 43-86, 112-172, 292-394), exec'd from its files (their modules
+    import h5py / colorama, absent here), driving the reference's three model classes on a synthetic test list.
+    Seeds are recorded: with rnn.draws = "host" the modules of supernnova_amd draw eps / masks with the same torch
+    calls in the same order, so seeding alike replays every output."""
+    import math
+    import pandas as pd
+    from sklearn import metrics
+    R = "/root/reference/python/supernnova"
+    feats = ([f"FLUXCAL_{f}" for f in "griz"] + [f"FLUXCALERR_{f}" for f in "griz"] + ["delta_time"] +
+             ["g", "gi", "gir", "girz", "giz", "gr", "grz", "gz", "i", "ir", "irz", "iz", "r", "rz", "z"])
+    arr_norm = np.array([[-10.0, 3.2, 0.9]] * 4 + [[0.0, 1.0, 0.5]] * 4 + [[0.0, 0.9, 0.8]], np.float64)
+    tun = {"np": np, "torch": torch, "nn": torch.nn, "metrics": metrics}
+    _grab(f"{R}/utils/training_utils.py", {"get_data_batch", "unnormalize_arr", "eval_step", "get_evaluation_metrics"}, tun)
+    du = SimpleNamespace(OFFSETS_STR=["-7", "-2", "-1", "", "+1", "+2", "+30"], OFFSETS_VAL=[-7, -2, -1, 0, 1, 2, 30],
+                         OOD_TYPES=["random", "reverse", "shuffle", "sin"])
+    data, peak = g10_data(40, 91, feats, arr_norm)
+    out = dict(features=np.array(feats), arr_norm=arr_norm, n=np.int64(len(data)),
+               lengths=np.array([d[0].shape[0] for d in data], np.int64), x=np.concatenate([d[0] for d in data]),
+               x_all=np.concatenate([d[3] for d in data]), target=np.array([d[1] for d in data], np.int64),
+               snid=np.array([d[2] for d in data]), peak=np.array([peak[d[2]] for d in data], np.float64))
+    for model, cls in (("vanilla", vanilla_rnn.VanillaRNN), ("variational", variational_rnn.VariationalRNN),
+                       ("bayesian", bayesian_rnn.BayesianRNN)):
+        st = g10_settings(model, feats, arr_norm)
+        torch.manual_seed(61)
+        rnn = build(cls, len(feats), st)
+        if model == "bayesian":
+            with torch.no_grad():
+                for n_, p_ in rnn.named_parameters():
+                    if "mu" in n_:
+                        p_.mul_(6.0)
+        rnn.eval()
+        out[f"{model}/sd"] = sd_np(rnn)
+        # ---- a10: get_evaluation_metrics, full list and a sampled subset
+        np.random.seed(17)
+        torch.manual_seed(1700)
+        m_full = tun["get_evaluation_metrics"](st, data, rnn)
+        np.random.seed(18)
+        torch.manual_seed(1800)
+        m_sub = tun["get_evaluation_metrics"](st, data, rnn, sample_size=20)
+        for tag, m in (("full", m_full), ("sub", m_sub)):
+            out[f"{model}/metrics_{tag}"] = np.array([m["AUC"], m["Acc"], m["loss"], m.get("KL", np.nan)], np.float64)
+        # ---- a12 / f2: the MC and MFE passes of get_predictions
+        ns = {"np": np, "torch": torch, "nn": torch.nn, "pd": pd, "math": math, "du": du,
+              "tu": SimpleNamespace(get_data_batch=tun["get_data_batch"]), "tqdm": lambda it, **kw: it}
+        _grab(f"{R}/validation/validate_rnn.py",
+              {"find_idx", "construct_predict_dict", "flatten_to_dataframe", "get_aggregated_dataframe",
+               "get_batch_predictions", "get_batch_predictions_MFE", "dispatch_batch_predictions"}, ns)
+        _grab_nested(f"{R}/validation/validate_rnn.py", "get_predictions", "_populate_predict_dict", ns)
+        if model == "vanilla":
+            st.num_inference_samples = 1
+        S = st.num_inference_samples
+        num_elem = len(data)
+        ns.update(settings=st, list_data_test=data,
+                  list_batches=np.array_split(np.arange(num_elem), num_elem / min(num_elem, st.batch_size)),
+                  df_SNinfo=pd.DataFrame({"SNID": [d[2] for d in data], "PEAKMJDNORM": [peak[d[2]] for d in data]}).set_index("SNID"))
+        d_pred = ns["construct_predict_dict"](num_elem, S, st.nb_classes)
+        d_mfe = ns["construct_predict_dict"](num_elem, 1, st.nb_classes, MFE=True)
+        np.random.seed(19)
+        torch.manual_seed(1900)
+        ns["_populate_predict_dict"](rnn, d_pred, S)
+        ns["_populate_predict_dict"](rnn, d_mfe, 1, _mode="MFE")
+        for k, v in d_pred.items():
+            out[f"{model}/pred/{k}"] = v
+        for k, v in d_mfe.items():
+            out[f"{model}/pred_mfe/{k}"] = v
+        df = ns["flatten_to_dataframe"](d_pred)
+        out[f"{model}/df_columns"] = np.array(list(df.columns))
+        out[f"{model}/df_all_class1"] = df["all_class1"].values
+        if model != "vanilla":
+            agg = ns["get_aggregated_dataframe"](df)
+            out[f"{model}/agg_columns"] = np.array(list(agg.columns))
+            out[f"{model}/agg_index"] = np.array(agg.index.values)
+            num = [c for c in agg.columns if c != "SNID"]
+            out[f"{model}/agg_numeric_columns"] = np.array(num)
+            out[f"{model}/agg_values"] = agg[num].values.astype(np.float64)
+        nan_share = float(np.isnan(d_pred["PEAKMJD-7"][:, 0, 0]).mean())
+        print(f"  g10 {model}: metrics full {m_full}, sub {m_sub}; PEAKMJD-7 empty for {nan_share:.0%} of curves")
+    flat = {}
+    for k, v in out.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}/{kk}"] = np.asarray(vv)
+            continue
+        flat[k] = np.asarray(v)
+        if flat[k].dtype == object:
+            flat[k] = flat[k].astype(str)
+    path = os.path.join(OUT, "g10_predictions.npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+# ---------------------------------------------------------------- G11 database loader
+def g11_loader():
+    """f3 (host logic): the reference's own load_HDF5 / fill_data_list / normalize_arr / unnormalize_arr
+    (utils/training_utils.py:23-124, 127-317) and load_HDF5_SNinfo (utils/data_utils.py:427-455), exec'd from its
+    files with `h5py.File` bound to a dict stand-in (tests/util.FakeH5) over a synthetic database of the datasets
+    save_to_HDF5 writes.  Expected outputs only: the database is regenerated from its seed in the test."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import synthetic_database, loader_settings, fake_h5
+    R = "/root/reference/python/supernnova"
+    db, feats = synthetic_database()
+    quiet = SimpleNamespace(print_green=lambda *a, **k: None, print_red=lambda *a, **k: None)
+    ns = {"np": np, "h5py": SimpleNamespace(File=lambda path, mode="r": fake_h5(db)), "lu": quiet,
+          "tqdm": lambda it, **kw: it}
+    _grab(f"{R}/utils/training_utils.py", {"normalize_arr", "unnormalize_arr", "fill_data_list", "load_HDF5"}, ns)
+    dns = {"np": np, "pd": pd, "h5py": ns["h5py"]}
+    _grab(f"{R}/utils/data_utils.py", {"load_HDF5_SNinfo"}, dns)
+    out = {}
+    for tag, kw in (("global", {}), ("zspe", dict(redshift="zspe")), ("cosmo", dict(norm="cosmo")),
+                    ("quantile", dict(norm="cosmo_quantile")), ("none", dict(norm="none")), ("c7", dict(nb_classes=7))):
+        st = loader_settings(feats, **kw)
+        test = ns["load_HDF5"](st, test=True)
+        out[f"{tag}/test_snid"] = np.array([t[2] for t in test])
+        out[f"{tag}/test_target"] = np.array([t[1] for t in test], np.int64)
+        out[f"{tag}/test_lengths"] = np.array([t[0].shape[0] for t in test], np.int64)
+        for j, name in ((0, "x_normed"), (3, "x_all"), (4, "x_ori")):
+            out[f"{tag}/test_{name}"] = np.concatenate([t[j] for t in test]).astype(np.float32)
+        assert all(t[0].dtype == np.float32 for t in test)
+        np.random.seed(5)
+        train, val = ns["load_HDF5"](st)
+        for nm, lst in (("train", train), ("val", val)):
+            out[f"{tag}/{nm}_snid"] = np.array([t[2] for t in lst])
+            out[f"{tag}/{nm}_target"] = np.array([t[1] for t in lst], np.int64)
+            out[f"{tag}/{nm}_x_normed"] = np.concatenate([t[0] for t in lst]).astype(np.float32)
+        out[f"{tag}/data_types_training"] = np.asarray(st.data_types_training).astype(str)
+        print(f"  g11 {tag}: test {len(test)}, train {len(train)}, val {len(val)} curves")
+    info = dns["load_HDF5_SNinfo"](loader_settings(feats))
+    out["sninfo_columns"] = np.array(list(info.columns))
+    out["sninfo_snid"] = info["SNID"].values.astype(str)
+    out["sninfo_peak"] = info["PEAKMJDNORM"].values
+    path = os.path.join(OUT, "g11_loader.npz")
+    np.savez_compressed(path, **{k: (v.astype(str) if v.dtype == object else v) for k, v in out.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
 # ---------------------------------------------------------------- G7 on-the-fly (broker) path
 def _grab(path, names, ns):
     """exec the named top-level functions of a reference file (its module imports h5py/astropy/colorama,
@@ -653,7 +908,7 @@ def g8_swag():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("SNN_GOLDEN_THREADS", "8")))   # tiny batches: 1 thread is fastest
     which = sys.argv[1:] or ["g0", "g1", "g2", "g3", "g4", "g5", "g7", "g8", "g9"]
     if "g0" in which:
         g0_init()
@@ -667,8 +922,15 @@ if __name__ == "__main__":
         g4_train()
     if "g5" in which:
         g5_mc_stats()
+    for model in ("bayesian", "variational"):
+        if f"g5gate_{model}" in which:
+            g5_gate(model)
     if "g7" in which:
         g7_onthefly()
+    if "g10" in which:
+        g10_predictions()
+    if "g11" in which:
+        g11_loader()
     if "g8" in which:
         g8_swag()
     if "g9" in which:
