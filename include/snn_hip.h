@@ -140,6 +140,10 @@ typedef struct snn_masks {
 
 const char *snn_last_error(void);
 int snn_version(void);
+/* Name, template arguments and launch geometry of the forward kernel the calling thread dispatched last
+ * (snn_lstm_forward / _noalloc / _train), e.g. "lstm_fwd_pair_kernel<32,12,2,plain> grid=768 block=256 lds=...";
+ * "" before the first launch.  For reports: benchmarks print what ran instead of a hard-coded name. */
+const char *snn_last_forward_kernel(void);
 
 /* ---- sizes (host only, no device access) -------------------------------- */
 int64_t snn_param_count(const snn_cfg *cfg);  /* P: canonical flat floats incl. head bias, <0 on error */
@@ -254,6 +258,28 @@ int snn_lstm_forward(const snn_cfg *cfg, const float *xp, const int32_t *len_sor
                      float *out_logits, float *out_probs, int64_t out_stride_sample,
                      int64_t out_stride_curve, void *workspace, int64_t workspace_bytes,
                      void *stream);
+
+/*
+ * snn_lstm_forward for callers that cannot allocate.  No counterpart in the reference: it exists for callers of this
+ * library that may not call hipMalloc around the launch -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation -- and therefore cannot provide (or size) a workspace.  Same arguments, results
+ * and errors as snn_lstm_forward minus workspace / workspace_bytes: the work-queue heads and the layer-output slabs
+ * live in a device array of the library, SNN_NOALLOC_SCRATCH_BYTES (64 MiB) on every GPU the library runs on, held
+ * until the process ends.  The persistent grid is cut to the number of per-workgroup slabs that fit
+ * (dirs * max_T * H * 32 * 4 bytes per tile in flight: 102 workgroups at H=32, max_T=40; results do not depend on the
+ * grid); a (cfg, max_T) whose single slab exceeds the scratch returns SNN_ERR_WORKSPACE.  The call itself performs no
+ * hipMalloc / hipFree (nor does any other entry point: here there is also no caller allocation to size).  All calls on
+ * one GPU share that GPU's array: calls that overlap on one GPU (different streams) race -- serialise them.
+ */
+#define SNN_NOALLOC_SCRATCH_BYTES (64ll << 20)
+#define SNN_NOALLOC_MAX_DEVICES 64
+int64_t snn_lstm_forward_noalloc_scratch_bytes(void);
+int snn_lstm_forward_noalloc(const snn_cfg *cfg, const float *xp, const int32_t *len_sorted,
+                             const int32_t *order, const int32_t *tile_T, const int64_t *tile_off,
+                             int32_t n_curves, int32_t n_tiles, int32_t max_T, const float *wk,
+                             int64_t wk_sample_stride, int32_t n_samples, const snn_masks *masks,
+                             float *out_logits, float *out_probs, int64_t out_stride_sample,
+                             int64_t out_stride_curve, void *stream);
 
 /* ---- training ------------------------------------------------------------- */
 

@@ -72,6 +72,10 @@ SIGNATURES = {
                                         ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64,
                                         _P, ctypes.c_int64, _P]),
     "snn_train_tape_floats": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
+    "snn_lstm_forward_noalloc_scratch_bytes": (ctypes.c_int64, []),
+    "snn_lstm_forward_noalloc": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
     "snn_lstm_forward_train": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, _P, ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64,
                                               _P, ctypes.c_int64, _P]),

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -538,6 +539,25 @@ static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g
     HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, g->threads, g->lds));
     per_cu = std::max(1, std::min(per_cu, 8));
+// snn_lstm_forward_noalloc: the workspace is a fixed scratch, so the persistent grid shrinks to the number of
+// per-workgroup slabs that fit (any grid >= 1 drains the work queue; results do not depend on the grid)
+static int fit_grid_to_workspace(FwdGeom* g, int64_t header, int64_t workspace_bytes, int max_T)
+{
+    const int64_t per_wg = (g->ws_bytes - header) / g->grid;
+    const int64_t cap = per_wg > 0 ? (workspace_bytes - header) / per_wg : g->grid;
+    if (cap < 1) {
+        snn_set_error("snn_lstm_forward_noalloc: one workgroup's layer-output slab for max_T=%d is %lld bytes, beyond the "
+                      "%lld-byte scratch of this entry point: use snn_lstm_forward with a caller workspace",
+                      max_T, (long long)per_wg, (long long)(workspace_bytes - header));
+        return SNN_ERR_WORKSPACE;
+    }
+    if (cap < g->grid) {
+        g->grid = (int)cap;
+        g->ws_bytes = header + per_wg * cap;
+    }
+    return SNN_OK;
+}
+
     g->grid = cus * per_cu;
     g->cus = cus;
     g->nbuf = y.L > 2 ? 2 : 1;
@@ -550,7 +570,8 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
                              const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles,
                              int32_t max_T, const float* wk, int64_t wk_sample_stride, int32_t n_samples,
                              const snn_masks* masks, float* out_logits, float* out_probs, int64_t out_stride_sample,
-                             int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream)
+                             int64_t out_stride_curve, void* workspace, int64_t workspace_bytes, void* stream,
+                             bool fit_grid)
 {
     const bool masked = masks && masks->mode != SNN_MASK_NONE;
     if (masked && (y.prec != 2 || masks->mid_T != 1)) {
@@ -584,6 +605,7 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     if (rc) return rc;
     p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
     p.counter = (unsigned int*)workspace;                 // 8 per-XCD queue heads, 64 bytes apart
+    if (fit_grid && (rc = fit_grid_to_workspace(&g, 1024, workspace_bytes, max_T))) return rc;
     p.yscratch = (float*)((char*)workspace + 1024);
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
@@ -664,7 +686,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                           int32_t n_tiles, int32_t max_T, const float* wk, int64_t wk_sample_stride,
                           int32_t n_samples, const snn_masks* masks, float* out_logits, float* out_probs,
                           int64_t out_stride_sample, int64_t out_stride_curve, float* tape, int64_t tape_floats,
-                          void* workspace, int64_t workspace_bytes, void* stream)
+                          void* workspace, int64_t workspace_bytes, void* stream, bool fit_grid = false)
 {
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
@@ -690,7 +712,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     if (y.prec != 0)
         return launch_forward_b3(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, wk_sample_stride,
                                  n_samples, masks, out_logits, out_probs, out_stride_sample, out_stride_curve, workspace,
-                                 workspace_bytes, stream);
+                                 workspace_bytes, stream, fit_grid);
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (train && (!tape || n_samples != 1 || tape_floats < tape_tile * n_tiles)) {
         snn_set_error("snn_lstm_forward_train: tape missing or too small (%lld < %lld floats) or n_samples != 1",
@@ -729,6 +751,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
     p.tape = tape; p.tape_tile = tape_tile;
+    if (fit_grid && (rc = fit_grid_to_workspace(&g, 256, workspace_bytes, max_T))) return rc;
     hipStream_t st = (hipStream_t)stream;
     // small training batches: one launch per layer with the two directions side by side (snn_fwd_small.h)
     const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * y.NW * y.C * 32;
@@ -782,3 +805,47 @@ extern "C" int snn_lstm_forward_train(const snn_cfg* cfg, const float* xp, const
                           masks, out_logits, nullptr, 0, cfg ? cfg->nb_classes : 0, tape, tape_floats, workspace,
                           workspace_bytes, stream);
 }
+// ---- the one entry point that allocates nothing (include/snn_hip.h) ---------------------------------------
+// Work-queue heads + layer-output slabs live in this file-scope array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy at its own address: the address is looked up once per device (with that device
+// current) and only that pointer -- never the symbol -- is handed to hipMemsetAsync and the kernels.
+static __device__ __align__(256) unsigned char scratch[SNN_NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[SNN_NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int noalloc_scratch(void** out)
+{
+    int dev = -1;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SNN_NOALLOC_MAX_DEVICES) {
+        snn_set_error("snn_lstm_forward_noalloc: device ordinal %d outside [0, %d)", dev, SNN_NOALLOC_MAX_DEVICES);
+        return SNN_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) { snn_set_error("snn_lstm_forward_noalloc: hipGetSymbolAddress returned a null scratch address"); return SNN_ERR_HIP; }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return SNN_OK;
+}
+
+extern "C" int64_t snn_lstm_forward_noalloc_scratch_bytes(void) { return SNN_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int snn_lstm_forward_noalloc(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
+                                        const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
+                                        int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
+                                        int64_t wk_sample_stride, int32_t n_samples, const snn_masks* masks,
+                                        float* out_logits, float* out_probs, int64_t out_stride_sample,
+                                        int64_t out_stride_curve, void* stream)
+{
+    void* ws = nullptr;
+    int rc = noalloc_scratch(&ws);
+    if (rc) return rc;
+    return launch_forward(cfg, false, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk,
+                          wk_sample_stride, n_samples, masks, out_logits, out_probs, out_stride_sample,
+                          out_stride_curve, nullptr, 0, ws, SNN_NOALLOC_SCRATCH_BYTES, stream, /*fit_grid=*/true);
+}
+

@@ -332,6 +332,38 @@ def lstm_forward_train(cfg, plan, xp, wk, masks=None):
     mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
     ws = _workspace(cfg, plan.max_T, dev)
     L.check(L.load().snn_lstm_forward_train(
+def last_forward_kernel():
+    """Name + launch geometry of the forward kernel this thread dispatched last (snn_last_forward_kernel)."""
+    return (L.load().snn_last_forward_kernel() or b"").decode()
+
+
+def lstm_forward_noalloc(cfg, plan, xp, wk, n_samples, logits=None, probs=None, masks=None, sample_major=True):
+    """snn_lstm_forward_noalloc: as lstm_forward, but nothing is allocated -- the caller passes the output tensors
+    (either may be None) and the library's own fixed device scratch replaces the workspace (include/snn_hip.h)."""
+    _require_cuda(xp, "xp")
+    _require_cuda(wk, "wk")
+    N, C, S = plan.n_curves, cfg.nb_classes, n_samples
+    stride = 0 if wk.dim() == 1 else cfg.PK
+    if (wk.dim() == 1 and wk.numel() != cfg.PK) or (wk.dim() != 1 and wk.shape != (S, cfg.PK)):
+        raise L.SnnError(f"wk shape {tuple(wk.shape)} matches neither ({cfg.PK},) nor ({S},{cfg.PK})")
+    if xp.numel() != plan.packed_floats(cfg):
+        raise L.SnnError("xp does not match the plan")
+    shape = (S, N, C) if sample_major else (N, S, C)
+    os_s, os_n = (N * C, C) if sample_major else (C, S * C)
+    for t, n in ((logits, "logits"), (probs, "probs")):
+        if t is not None:
+            _require_cuda(t, n)
+            if tuple(t.shape) != shape:
+                raise L.SnnError(f"{n} shape {tuple(t.shape)} != {shape}")
+    mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
+    L.check(L.load().snn_lstm_forward_noalloc(
+        ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
+        _ptr(plan.d_tile_off), N, plan.n_tiles, plan.max_T, _ptr(wk), stride, S,
+        ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(probs), os_s, os_n, _stream()),
+        "snn_lstm_forward_noalloc")
+    return logits, probs
+
+
         ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
         _ptr(plan.d_tile_off), plan.n_curves, plan.n_tiles, plan.max_T, _ptr(wk),
         ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(tape), tape.numel(),
