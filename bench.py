@@ -114,6 +114,85 @@ def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves, model="bayesia
     return n_curves / dt, dt
 
 
+def end_to_end(E, cfg, x, lengths, lengths_host, mu, rho, prior, S, steps, dev):
+    """the PCIe-inclusive rate -- ragged rows in pinned HOST memory -> H2D -> plan / pack / sample /
+    forward -> D2H of the (N, S, C) probabilities into pinned host memory.  Three streams (upload of step i+1 and
+    download of step i-1 beside the forward of step i; two device row buffers).  Reported beside `value`, never as it."""
+    N, T, C = x.size(1), x.size(0), cfg.nb_classes
+    keep = torch.arange(T, device=dev).unsqueeze(0) < lengths.unsqueeze(1)            # (N, T)
+    rows_h = x.permute(1, 0, 2)[keep].cpu().pin_memory()                              # (sum len, D), curve-major
+    del keep
+    off_h = torch.from_numpy(np.concatenate([[0], np.cumsum(lengths_host.astype(np.int64))[:-1]])
+                             * cfg.input_size).pin_memory()
+    probs_h = torch.empty((N, S, C), dtype=torch.float32).pin_memory()
+    up, down, main_s = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()
+    bufs = [(torch.empty(rows_h.shape, dtype=torch.float32, device=dev),
+             torch.empty(off_h.shape, dtype=torch.int64, device=dev)) for _ in range(2)]
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def upload(i):
+        b = i % 2
+        with torch.cuda.stream(up):
+            up.wait_event(consumed[b])              # the pack of step i-2 has read this buffer
+            bufs[b][0].copy_(rows_h, non_blocking=True)
+            bufs[b][1].copy_(off_h, non_blocking=True)
+            uploaded[b].record(up)
+
+    def run(K, first):
+        upload(first)
+        for i in range(first, first + K):
+            b = i % 2
+            main_s.wait_event(uploaded[b])
+            plan = E.Plan(cfg, lengths_host, dev)
+            xp = E.pack_ragged(cfg, plan, bufs[b][0], bufs[b][1])
+            consumed[b].record(main_s)
+            if i + 1 < first + K:
+                upload(i + 1)
+            wk, _ = E.bbb_sample(cfg, mu, rho, S, prior, seed=1234, offset=i * S)
+            _, probs = E.lstm_forward(cfg, plan, xp, wk, S, want_logits=False, want_probs=True, sample_major=False)
+            done = torch.cuda.Event()
+            done.record(main_s)
+            with torch.cuda.stream(down):
+                down.wait_event(done)
+                probs_h.copy_(probs.view(N, S, C), non_blocking=True)
+                probs.record_stream(down)
+        torch.cuda.synchronize()
+        return probs
+
+    for e in consumed:
+        e.record(main_s)
+    run(1, 0)
+    t0 = time.perf_counter()
+    probs = run(steps, 2)
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.equal(probs_h[:1000], probs[:1000].cpu())) and bool(torch.isfinite(probs_h[-1000:]).all())
+    return {"value": N / dt, "unit": "light curves/s", "ms_per_step": 1e3 * dt,
+            "h2d_bytes": rows_h.numel() * 4 + off_h.numel() * 8, "d2h_bytes": probs_h.numel() * 4,
+            "what": "pinned host rows -> H2D -> plan/pack/sample/forward -> D2H of (N,S,C) into pinned host memory; copies "
+                    "on their own streams beside the forward kernel (microbench/pcie_inclusive.py)"}
+
+
+def cpu_baseline_full(cfg, x, lengths_host, mu, rho, S):
+    """BASELINE.md 3 protocol (minutes of CPU work; --cpu-full only): 12 800 curves = 100 batches of 128, median of 3
+    runs on all host threads this process was given, plus a 1-thread figure on 1 280 curves."""
+    out = {"unit": "light curves/s", "kind": "port"}
+    n = 12800
+    xh, lh = x[:, :n].cpu().numpy(), lengths_host[:n]
+    threads = torch.get_num_threads()
+    runs = []
+    for r in range(3):
+        v, secs = cpu_baseline(cfg, xh, lh, mu, rho, S, n)
+        runs.append(v)
+        print(f"cpu baseline (full): run {r}: {v:.1f} curves/s in {secs:.0f} s on {threads} threads", file=sys.stderr, flush=True)
+    out.update(value=float(np.median(runs)), runs=runs, cores=threads, sample=f"{n} curves, median of 3")
+    torch.set_num_threads(1)
+    v1, secs = cpu_baseline(cfg, xh[:, :1280], lh[:1280], mu, rho, S, 1280)
+    torch.set_num_threads(threads)
+    out["one_thread"] = {"value": v1, "cores": 1, "sample": f"1280 curves, {secs:.0f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +210,11 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true",
                     help="skip the subset re-run after the timed region (profiling runs: keeps the kernel statistics to "
                          "the timed launches)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the PCIe-inclusive measurement the default (f32, des, 1 GPU) run appends as `end_to_end`")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also time the CPU port with the BASELINE.md 3 protocol (12 800 curves, median of 3, and 1 thread): "
+                         "several minutes of CPU work")
     ap.add_argument("--no-fast-path", action="store_true",
                     help="skip the extra f16x2 measurement the default (f32, des, 1 GPU) run appends as `fast_path`")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
@@ -205,6 +289,7 @@ def main():
     # i + 1 (a few ms of host work per 1.25 M curves) while the GPU runs step i, as a serving loop would
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     kern_ms = []
+    dispatched = [""]          # what snn_lstm_forward launched in the timed steps (snn_last_forward_kernel)
     from supernnova_amd import distributed as Dist
 
     def step(i, timed):
@@ -222,6 +307,7 @@ def main():
                                   sample_major=False)
         if timed:
             evs[i - args.warmup][1].record()
+            dispatched[0] = E.last_forward_kernel()
         # the only exchange of the inference path: per-curve mean / std over the S draws, (N_local, 2C),
         # reduced on the device and gathered to rank 0 -- inside the timed region
         std, mean = torch.std_mean(probs, dim=1, unbiased=True)
@@ -290,23 +376,24 @@ def main():
         achieved = fl / (k_ms * 1e-3) / 1e12
         b3 = args.precision != "f32"
         npr = 6 if args.precision == "bf16x3" else 3     # piece products per fp32 product
-        peak, kname = PEAK_FP32_MFMA_TFLOPS, ("lstm_fwd_big_kernel<128,39,2,false>" if big else
-                                              "lstm_fwd_pair_kernel<32,12,2,masked>" if var else "lstm_fwd_pair_kernel<32,12,2>")
+        peak, kname = PEAK_FP32_MFMA_TFLOPS, dispatched[0]
         if b3:
             # executed 16-bit MFMA FLOPs: 6 (bf16x3) / 3 (f16x2) piece products per fp32 product, K padded to blocks of 16
             H, Dp16 = cfg.hidden_size, -(-cfg.input_size // 16) * 16
             per_step = 2 * 4 * H * ((Dp16 + H) + (2 * H + H)) * 2 * npr
             fl_exec = S * int(lengths_host.astype(np.int64).sum()) * per_step
             achieved_f32eq, achieved = achieved, fl_exec / (k_ms * 1e-3) / 1e12
-            peak, kname = PEAK_BF16_MFMA_TFLOPS, ("lstm_fwd_b3p_kernel<32,2,2>" if npr == 6 else
-                                                  f"lstm_fwd_h2_kernel<32,2,2,{'true' if var else 'false'}>")
-        traffic = None   # PMC bytes per launch of this workload, from the committed rocprofv3 passes (profiles/)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
-            if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3 and not var:
-                traffic = tj["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+            peak = PEAK_BF16_MFMA_TFLOPS
+        # PMC bytes per launch of this workload: NOT measured in this run -- read from the committed rocprofv3 passes
+        traffic = traffic_src = None
+        for rnd in ("r2", "r1"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+                if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3 and not var:
+                    traffic, traffic_src = tj["traffic_bytes_per_launch"], f"profiles/{rnd}/traffic.json (rocprofv3 --pmc passes, not this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": ("light curves/s classified, VariationalRNN 50 MC samples" if var else
                        "light curves/s classified, BayesianRNN 50 MC samples"),
@@ -331,7 +418,7 @@ def main():
                        "backend": (backend if world > 1 else None)},
             "roofline": {"bound": "mfma",
                          "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": k_ms, "flop_per_launch": fl_exec if b3 else fl},
         }
         if b3:
@@ -358,9 +445,13 @@ def main():
             out["fast_path"] = {"precision": "f16x2 (each fp32 product = 3 fp16 piece products, fp32 accumulate; "
                                              "opt-in, same 1e-5 parity bar)",
                                 "value": N * args.steps / fdt, "unit": "light curves/s", "ms_per_step": 1e3 * fdt / args.steps,
-                                "kernel": "lstm_fwd_h2_kernel<32,2,2,false>", "kernel_ms": float(np.mean(fk)),
+                                "kernel": E.last_forward_kernel(), "kernel_ms": float(np.mean(fk)),
                                 "fp32_equivalent_tflops": fl / (float(np.mean(fk)) * 1e-3) / 1e12}
             del fxp, fwk, fprobs
+        if world == 1 and not b3 and not big and not var and not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(E, cfg, x, lengths, lengths_host, mu, rho, prior, S, args.steps, dev)
+        if args.cpu_full and world == 1:
+            out["cpu_baseline_full"] = cpu_baseline_full(cfg, x, lengths_host, mu, rho, S)
         if args.cpu_curves > 0 and world == 1:
             n_cpu = min(args.cpu_curves, N)
             if big and args.cpu_curves == 3840:

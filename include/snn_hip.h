@@ -331,12 +331,16 @@ int snn_bbb_backward(const snn_cfg *cfg, const float *mu, const float *rho, cons
 /*
  * Mean cross-entropy over n curves and dlogits = grad_scale * (softmax - onehot)  [grad_scale = 1/n
  * for the plain mean]; nn.CrossEntropyLoss at utils/training_utils.py:515 and its backward.
- * target int64 (n), loss: device scalar.  The sum is taken in a fixed order (per-workgroup partials added by index by
- * the workgroup that finishes last), so the loss does not depend on scheduling.  The partials live in one device array
- * of the library: calls that overlap on the same GPU (different streams) race; a training step uses one stream.
+ * target int64 (n), loss: device scalar.  The sum is taken in a fixed order (per-workgroup fp64 partials, added by
+ * index), so the loss does not depend on scheduling.  `partials`: caller-owned device scratch of
+ * snn_ce_loss_partials(n) doubles (0 for n <= 1024, where it may be NULL; 256 otherwise) -- the library keeps no state,
+ * so calls on different streams with different scratch may overlap.  A target outside [0, n_classes) -- where
+ * nn.CrossEntropyLoss raises, and train_rnn.py:318-323 raises ValueError beforehand -- makes the loss NaN and zeroes
+ * that curve's row of dlogits (no out-of-bounds read).
  */
+int64_t snn_ce_loss_partials(int32_t n);
 int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float *logits, const int64_t *target,
-                     float grad_scale, float *loss, float *dlogits, void *stream);
+                     float grad_scale, float *loss, float *dlogits, double *partials, void *stream);
 
 
 /*

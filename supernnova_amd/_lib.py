@@ -52,6 +52,7 @@ _I64P = ctypes.POINTER(ctypes.c_int64)
 SIGNATURES = {
     "snn_last_error": (ctypes.c_char_p, []),
     "snn_version": (ctypes.c_int, []),
+    "snn_last_forward_kernel": (ctypes.c_char_p, []),
     "snn_param_count": (ctypes.c_int64, [_CFG]),
     "snn_kparam_count": (ctypes.c_int64, [_CFG]),
     "snn_feat": (ctypes.c_int32, [_CFG]),
@@ -71,11 +72,11 @@ SIGNATURES = {
                                         ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64,
                                         _P, ctypes.c_int64, _P]),
-    "snn_train_tape_floats": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
     "snn_lstm_forward_noalloc_scratch_bytes": (ctypes.c_int64, []),
     "snn_lstm_forward_noalloc": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,
                                                 ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64, ctypes.c_int64, _P]),
+    "snn_train_tape_floats": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
     "snn_lstm_forward_train": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                               ctypes.c_int32, _P, ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64,
                                               _P, ctypes.c_int64, _P]),
@@ -85,7 +86,8 @@ SIGNATURES = {
                                          _P, ctypes.c_int64, _P]),
     "snn_bbb_backward": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                         ctypes.POINTER(SnnPrior), _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_int32, _P]),
-    "snn_ce_loss_grad": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, _P, ctypes.c_float, _P, _P, _P]),
+    "snn_ce_loss_partials": (ctypes.c_int64, [ctypes.c_int32]),
+    "snn_ce_loss_grad": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, _P, ctypes.c_float, _P, _P, _P, _P]),
     "snn_adam_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 6 + [_P]),
 }
 

@@ -31,14 +31,16 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
                                                      const int32_t* __restrict__ len_sorted,
                                                      const int32_t* __restrict__ tile_T,
                                                      const int64_t* __restrict__ tile_off,
-                                                     __bf16* __restrict__ xp)
+                                                     __bf16* __restrict__ xp, int64_t xp_words)
 {
     // one thread per 16-byte output word: 8 consecutive features of one curve at one step, read as 32 contiguous
     // bytes, written as NPC full words (lanes of a wave write consecutive words)
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
     const int64_t step_u4 = (int64_t)XB * NPC * 64;
-    uint4* dst = reinterpret_cast<uint4*>(xp) + tile_off[tile] / ((int64_t)Dp * SNN_TILE) * step_u4;
+    const int64_t step0 = tile_off[tile] / ((int64_t)Dp * SNN_TILE);
+    if ((step0 + T) * step_u4 * 4 > xp_words) return;   // caller's buffer is smaller than the plan: never write past it
+    uint4* dst = reinterpret_cast<uint4*>(xp) + step0 * step_u4;
     for (int idx = threadIdx.x; idx < T * XB * 64; idx += blockDim.x) {
         const int t = idx / (XB * 64), r = idx - t * (XB * 64), b = r >> 6, lp = r & 63, c = lp & 31;
         const int pos = tile * SNN_TILE + c;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
                                                     const int32_t* __restrict__ len_sorted,
                                                     const int32_t* __restrict__ tile_T,
                                                     const int64_t* __restrict__ tile_off,
-                                                    float* __restrict__ xp)
+                                                    float* __restrict__ xp, int64_t xp_words)
 {
     extern __shared__ float pk_lds[];
     __shared__ int64_t s_base[SNN_TILE];
@@ -84,6 +86,7 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
     const int tile = blockIdx.x;
     const int T = tile_T[tile];
     float* dst = xp + tile_off[tile];
+    if (tile_off[tile] + (int64_t)T * SNN_TILE * Dp > xp_words) return;   // buffer smaller than the plan: never write past it
     if (threadIdx.x < SNN_TILE) {
         const int pos = tile * SNN_TILE + threadIdx.x;
         const int orig = order[pos];
@@ -265,6 +268,9 @@ void snn_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* snn_last_error(void) { return g_err; }
+// name and launch geometry of the forward kernel this thread dispatched last (reports and benchmarks name what ran)
+static thread_local char g_last_kernel[160] = "";
+extern "C" const char* snn_last_forward_kernel(void) { return g_last_kernel; }
 extern "C" int snn_version(void) { return 100; }
 
 int snn_make_layout(const snn_cfg* cfg, SnnLayout* y)
@@ -406,17 +412,25 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
         snn_set_error("snn_pack_x: null pointer or bad size");
         return SNN_ERR_ARG;
     }
-    (void)xp_floats;
+    // xp_floats is the caller's statement of the buffer size in 4-byte words.  The exact need (total tile-steps x
+    // snn_x_step_floats) is only known from the DEVICE plan arrays, so the host checks the lower bound (one step per
+    // tile) and the kernels refuse to write a tile that would end beyond xp_floats.
+    const int64_t step_words = y.prec != 0 ? (int64_t)y.XB[0] * y.NPC * 64 * 4 : (int64_t)y.Dp * SNN_TILE;
+    if (xp_floats < (int64_t)n_tiles * step_words) {
+        snn_set_error("snn_pack_x: xp_floats %lld < %d tiles x %lld words per tile-step", (long long)xp_floats, n_tiles,
+                      (long long)step_words);
+        return SNN_ERR_ARG;
+    }
     if (y.prec != 0) {
         hipLaunchKernelGGL(y.prec == 1 ? pack_x3_kernel<3> : pack_x3_kernel<2>, dim3(n_tiles), dim3(256), 0,
                            (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t, stride_n, curve_off, order, len_sorted,
-                           tile_T, tile_off, reinterpret_cast<__bf16*>(xp));
+                           tile_T, tile_off, reinterpret_cast<__bf16*>(xp), xp_floats);
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
     hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256),
                        sizeof(float) * PACK_TS * y.Dp * (SNN_TILE + 1), (hipStream_t)stream, y.D, y.Dp, x, stride_t,
-                       stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp);
+                       stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp, xp_floats);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }
@@ -525,20 +539,6 @@ static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, Fw
     return SNN_OK;
 }
 
-// ---- bf16 x 3 forward (SNN_PREC_BF16X3) ----------------------------------------------------------------
-static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g)
-{
-    const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
-    g->threads = y.H * 8;
-    const int G = y.prec == 2 ? SNN_H2_G : 4;   // tiles per work item (B3_G of the kernels)
-    g->lds = (size_t)(2 * XBM + 2 * HB) * y.NPC * 64 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
-    if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
-    int dev = 0, cus = 0, per_cu = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, g->threads, g->lds));
-    per_cu = std::max(1, std::min(per_cu, 8));
 // snn_lstm_forward_noalloc: the workspace is a fixed scratch, so the persistent grid shrinks to the number of
 // per-workgroup slabs that fit (any grid >= 1 drains the work queue; results do not depend on the grid)
 static int fit_grid_to_workspace(FwdGeom* g, int64_t header, int64_t workspace_bytes, int max_T)
@@ -558,6 +558,20 @@ static int fit_grid_to_workspace(FwdGeom* g, int64_t header, int64_t workspace_b
     return SNN_OK;
 }
 
+// ---- bf16 x 3 forward (SNN_PREC_BF16X3) ----------------------------------------------------------------
+static int b3_geom(const SnnLayout& y, fwd_b3_kernel_t fn, int max_T, FwdGeom* g)
+{
+    const int HB = y.H / 16, XBM = std::max(y.XB[0], y.dirs * HB);
+    g->threads = y.H * 8;
+    const int G = y.prec == 2 ? SNN_H2_G : 4;   // tiles per work item (B3_G of the kernels)
+    g->lds = (size_t)(2 * XBM + 2 * HB) * y.NPC * 64 * 16 + sizeof(float) * ((size_t)(y.NW + G) * y.C * 32 + y.NW * 32 + G * 64) + 16;
+    if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
+    int dev = 0, cus = 0, per_cu = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, g->threads, g->lds));
+    per_cu = std::max(1, std::min(per_cu, 8));
     g->grid = cus * per_cu;
     g->cus = cus;
     g->nbuf = y.L > 2 ? 2 : 1;
@@ -591,6 +605,7 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     FwdGeom g;
     int rc = b3_geom(y, fn, max_T, &g);
     if (rc) return rc;
+    if (fit_grid && (rc = fit_grid_to_workspace(&g, 1024, workspace_bytes, max_T))) return rc;
     if (workspace_bytes < g.ws_bytes) {
         snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
         return SNN_ERR_WORKSPACE;
@@ -605,7 +620,6 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     if (rc) return rc;
     p.out_logits = out_logits; p.out_probs = out_probs; p.os_s = out_stride_sample; p.os_n = out_stride_curve;
     p.counter = (unsigned int*)workspace;                 // 8 per-XCD queue heads, 64 bytes apart
-    if (fit_grid && (rc = fit_grid_to_workspace(&g, 1024, workspace_bytes, max_T))) return rc;
     p.yscratch = (float*)((char*)workspace + 1024);
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
@@ -616,6 +630,10 @@ static int launch_forward_b3(const SnnLayout& y, const float* xp, const int32_t*
     HIP_CHECK(hipMemsetAsync(workspace, 0, 1024, st));
     const int G = y.prec == 2 ? SNN_H2_G : 4;
     const int64_t n_items = (int64_t)((n_tiles + G - 1) / G) * n_samples;
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d,%d%s> grid=%d block=%d lds=%zu",
+             y.prec == 2 ? "lstm_fwd_h2_kernel" : (y.prec == 1 && n_tiles > 1 && snn_b3p_kernel(y.H, y.XB[0], y.dirs) == fn)
+             ? "lstm_fwd_b3p_kernel" : "lstm_fwd_b3_kernel", y.H, y.XB[0], y.dirs, y.prec == 2 ? (masked ? ",true" : ",false") : "",
+             (int)std::min<int64_t>(g.grid, n_items), g.threads, g.lds);
     hipLaunchKernelGGL(fn, dim3((int)std::min<int64_t>(g.grid, n_items)), dim3(g.threads), g.lds, st, p, o);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
@@ -733,6 +751,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     FwdGeom g;
     rc = fwd_geom(y, fn, e->big, max_T, &g, pair);
     if (rc) return rc;
+    if (fit_grid && (rc = fit_grid_to_workspace(&g, 256, workspace_bytes, max_T))) return rc;
     if (workspace_bytes < g.ws_bytes) {
         snn_set_error("snn_lstm_forward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.ws_bytes);
         return SNN_ERR_WORKSPACE;
@@ -751,7 +770,6 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     p.y_buf_floats = g.y_buf_floats;
     p.nbuf = g.nbuf;
     p.tape = tape; p.tape_tile = tape_tile;
-    if (fit_grid && (rc = fit_grid_to_workspace(&g, 256, workspace_bytes, max_T))) return rc;
     hipStream_t st = (hipStream_t)stream;
     // small training batches: one launch per layer with the two directions side by side (snn_fwd_small.h)
     const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * y.NW * y.C * 32;
@@ -768,6 +786,9 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
     const int64_t n_items = (int64_t)(pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d,%d,%s> grid=%d block=%d lds=%zu",
+             pair ? "lstm_fwd_pair_kernel" : e->big ? "lstm_fwd_big_kernel" : "lstm_fwd_kernel", y.H, y.KKI[0], y.dirs,
+             train ? "train" : masked ? "masked" : "plain", grid, g.threads, g.lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds, st, p);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
@@ -785,26 +806,6 @@ extern "C" int snn_lstm_forward(const snn_cfg* cfg, const float* xp, const int32
                           out_stride_curve, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
-extern "C" int64_t snn_train_tape_floats(const snn_cfg* cfg, int32_t n_tiles, int32_t max_T)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    if (rc) return rc;
-    if ((rc = snn_lstm_only(y, "snn_train_tape_floats"))) return rc;
-    if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_train_tape_floats: bad sizes"); return SNN_ERR_ARG; }
-    return tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F) * n_tiles;
-}
-
-extern "C" int snn_lstm_forward_train(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
-                                      const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
-                                      int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
-                                      const snn_masks* masks, float* out_logits, float* tape, int64_t tape_floats,
-                                      void* workspace, int64_t workspace_bytes, void* stream)
-{
-    return launch_forward(cfg, true, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, 0, 1,
-                          masks, out_logits, nullptr, 0, cfg ? cfg->nb_classes : 0, tape, tape_floats, workspace,
-                          workspace_bytes, stream);
-}
 // ---- the one entry point that allocates nothing (include/snn_hip.h) ---------------------------------------
 // Work-queue heads + layer-output slabs live in this file-scope array instead of a caller workspace.  Every GPU the
 // library runs on holds its own copy at its own address: the address is looked up once per device (with that device
@@ -849,3 +850,23 @@ extern "C" int snn_lstm_forward_noalloc(const snn_cfg* cfg, const float* xp, con
                           out_stride_curve, nullptr, 0, ws, SNN_NOALLOC_SCRATCH_BYTES, stream, /*fit_grid=*/true);
 }
 
+extern "C" int64_t snn_train_tape_floats(const snn_cfg* cfg, int32_t n_tiles, int32_t max_T)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if ((rc = snn_lstm_only(y, "snn_train_tape_floats"))) return rc;
+    if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_train_tape_floats: bad sizes"); return SNN_ERR_ARG; }
+    return tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F) * n_tiles;
+}
+
+extern "C" int snn_lstm_forward_train(const snn_cfg* cfg, const float* xp, const int32_t* len_sorted,
+                                      const int32_t* order, const int32_t* tile_T, const int64_t* tile_off,
+                                      int32_t n_curves, int32_t n_tiles, int32_t max_T, const float* wk,
+                                      const snn_masks* masks, float* out_logits, float* tape, int64_t tape_floats,
+                                      void* workspace, int64_t workspace_bytes, void* stream)
+{
+    return launch_forward(cfg, true, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, 0, 1,
+                          masks, out_logits, nullptr, 0, cfg ? cfg->nb_classes : 0, tape, tape_floats, workspace,
+                          workspace_bytes, stream);
+}

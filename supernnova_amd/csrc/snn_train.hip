@@ -50,10 +50,26 @@ static const BwdEntry* find_bwd(const SnnLayout& y)
 static bool use_split_path(const SnnLayout& y, const BwdEntry* fused, int n_tiles)
 {
     if (!fused) return true;
-    static const char* force = getenv("SNN_BWD_PATH");
+    const char* force = getenv("SNN_BWD_PATH");
     if (force && force[0] == 'f') return false;
     if (force && force[0] == 's') return true;
     return n_tiles <= 8192;
+}
+// H = 32, round 2: the streamed path (snn_train_big.hip: bwd_stream_kernel) -- one pass over the tape per (layer,
+// direction), dG kept in LDS, dW accumulated in registers over a fixed stripe of tiles.  It moves half the bytes of
+// the split path and needs no workspace that grows with the gate gradients; it is the default wherever it exists.
+// SNN_BWD_PATH=split|fused selects the round-1 paths (A/B measurements and the equivalence tests).
+bool snn_bwd_stream_supported(const SnnLayout& y);
+int64_t snn_bwd_stream_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T);
+int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
+                             const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles, int32_t max_T,
+                             const float* wk, const MaskP& mk, const float* tape, int64_t tape_tile, const float* dlogits,
+                             float* dflat, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+static bool use_stream_path(const SnnLayout& y)
+{
+    const char* force = getenv("SNN_BWD_PATH");     // read per call: the tests switch paths inside one process
+    if (force && (force[0] == 'f' || (force[0] == 's' && force[1] == 'p'))) return false;
+    return snn_bwd_stream_supported(y);
 }
 // H = 64, 128: recurrent kernel + deferred GEMMs (snn_train_big.hip)
 bool snn_bwd_big_supported(const SnnLayout& y);
@@ -80,6 +96,7 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     if ((rc = snn_lstm_only(y, "snn_lstm_backward_workspace_bytes"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
     const BwdEntry* fused = find_bwd(y);
+    if (use_stream_path(y)) return snn_bwd_stream_workspace_bytes(y, n_tiles, max_T);
     if (use_split_path(y, fused, n_tiles)) {
         if (snn_bwd_big_supported(y)) return snn_bwd_big_workspace_bytes(y, n_tiles, max_T);
         snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs);
@@ -111,6 +128,13 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     }
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (tape_floats < tape_tile * n_tiles) { snn_set_error("snn_lstm_backward: tape too small"); return SNN_ERR_ARG; }
+    if (use_stream_path(y)) {
+        MaskP mk;
+        rc = snn_masks_to_device(masks, max_T, &mk);
+        if (rc) return rc;
+        return snn_lstm_backward_stream(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, mk, tape,
+                                        tape_tile, dlogits, dflat, accumulate, workspace, workspace_bytes, stream);
+    }
     if (use_split_path(y, e, n_tiles)) {
         MaskP mk;
         rc = snn_masks_to_device(masks, max_T, &mk);
@@ -228,17 +252,17 @@ extern "C" int snn_bbb_backward(const snn_cfg* cfg, const float* mu, const float
 // ============================================================================
 // Cross-entropy (mean over the batch) and its gradient w.r.t. the logits
 // (nn.CrossEntropyLoss() at utils/training_utils.py:515).  Up to CE_MAX_BLOCKS workgroups, each a fixed-order
-// partial sum in fp64 over its curves; the workgroup that finishes last adds the partials in index order, so the
-// loss does not depend on scheduling.  The partials live in a file-scope device array: calls that overlap on one
-// GPU (different streams) would race -- a training step is one stream.
+// partial sum in fp64 over its curves, written to the CALLER's `partials`; a one-thread kernel then adds the
+// partials in index order, so the loss does not depend on scheduling and the library keeps no state of its own.
+// A batch of up to 1024 curves is one workgroup and one launch.  A label outside [0, C) (torch raises there) makes
+// the loss NaN and zeroes that curve's gradient row.
 // ============================================================================
 #define CE_MAX_BLOCKS 256
-static __device__ double g_ce_partial[CE_MAX_BLOCKS];
-static __device__ unsigned int g_ce_done;
 
 __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const float* __restrict__ logits,
                                                           const int64_t* __restrict__ target, float scale,
-                                                          float* __restrict__ loss, float* __restrict__ dlogits)
+                                                          float* __restrict__ loss, float* __restrict__ dlogits,
+                                                          double* __restrict__ partials)
 {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -249,10 +273,12 @@ __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const f
         float z = 0.0f;
         for (int q = 0; q < C; ++q) z += expf(lg[q] - mx);
         const float lz = logf(z);
-        const int tq = (int)target[n];
-        acc += (double)(-(lg[tq] - mx - lz));
+        const int64_t t64 = target[n];
+        const bool valid = t64 >= 0 && t64 < C;
+        const int tq = valid ? (int)t64 : 0;
+        acc += valid ? (double)(-(lg[tq] - mx - lz)) : (double)NAN;
         for (int q = 0; q < C; ++q)
-            dlogits[(int64_t)n * C + q] = (expf(lg[q] - mx - lz) - (q == tq ? 1.0f : 0.0f)) * scale;
+            dlogits[(int64_t)n * C + q] = valid ? (expf(lg[q] - mx - lz) - (q == tq ? 1.0f : 0.0f)) * scale : 0.0f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
@@ -260,33 +286,38 @@ __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const f
     __syncthreads();
     if (threadIdx.x == 0) {
         const double part = sh[0] + sh[1] + sh[2] + sh[3];
-        if (gridDim.x == 1) {
-            *loss = (float)(part / (double)N);
-        } else {
-            __hip_atomic_store(&g_ce_partial[blockIdx.x], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int done = __hip_atomic_fetch_add(&g_ce_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (done == gridDim.x - 1) {
-                double tot = 0.0;
-                for (unsigned int b = 0; b < gridDim.x; ++b)
-                    tot += __hip_atomic_load(&g_ce_partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *loss = (float)(tot / (double)N);
-                __hip_atomic_store(&g_ce_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-            }
-        }
+        if (gridDim.x == 1) *loss = (float)(part / (double)N);
+        else partials[blockIdx.x] = part;
     }
 }
 
+__global__ void ce_loss_sum_kernel(int N, int blocks, const double* __restrict__ partials, float* __restrict__ loss)
+{
+    double tot = 0.0;
+    for (int b = 0; b < blocks; ++b) tot += partials[b];
+    *loss = (float)(tot / (double)N);
+}
+
+extern "C" int64_t snn_ce_loss_partials(int32_t n) { return n > 1024 ? CE_MAX_BLOCKS : 0; }
+
 extern "C" int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float* logits, const int64_t* target,
-                                float grad_scale, float* loss, float* dlogits, void* stream)
+                                float grad_scale, float* loss, float* dlogits, double* partials, void* stream)
 {
     if (!logits || !target || !loss || !dlogits || n < 1 || n_classes < 1) {
         snn_set_error("snn_ce_loss_grad: null pointer or bad size");
         return SNN_ERR_ARG;
     }
-    // one workgroup per 1024 curves (4 per thread): a batch of 128 stays a single workgroup, exactly as before
+    // one workgroup per 1024 curves (4 per thread): a batch of 128 stays a single workgroup and a single launch
     const int blocks = std::min(CE_MAX_BLOCKS, (n + 1023) / 1024);
+    if (blocks > 1 && (!partials || ((uintptr_t)partials & 7))) {
+        snn_set_error("snn_ce_loss_grad: n = %d > 1024 needs `partials` (snn_ce_loss_partials(n) = %d doubles, 8-byte aligned)",
+                      n, CE_MAX_BLOCKS);
+        return SNN_ERR_ARG;
+    }
     hipLaunchKernelGGL(ce_loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, n_classes, logits, target,
-                       grad_scale, loss, dlogits);
+                       grad_scale, loss, dlogits, partials);
+    if (blocks > 1)
+        hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, n, blocks, partials, loss);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }

@@ -474,6 +474,295 @@ __global__ void __launch_bounds__(256) chunk_reduce_kernel(int64_t n, int64_t P,
     out[i] = s;
 }
 
+// ---- streamed backward (H = 32): everything of one (layer, direction) in ONE pass over the tape -------------------
+// The split path above writes the gate gradients dG to HBM (16 KB per tile-step and direction) and reads them back
+// twice (bwd_dx, bwd_dw): at 65 536 curves that is 7 of the 13.5 GB the backward moves, and bwd_rec alone is HBM-bound.
+// Here a workgroup owns a direction and a fixed stripe of tiles (serpentine over the length-sorted tiles, so the
+// stripes carry equal work and the summation order is fixed), walks each tile's tape backwards and keeps dG_t in LDS:
+//   dh_{t-1}  = W_hh^T dG_t               16 MFMAs per wave (wave w owns gate rows 32w..32w+31 = its K range)
+//   dy_below  = W_ih^T dG_t  (layer > 0)  16 x DIRS MFMAs per wave, same B operand reads as the line above
+//   dW       += dG_t [h_{t-1} | x_t]^T    16 x (1 + NTX) MFMAs per wave, accumulators stay in registers for the whole
+//                                         stripe; the [h | x] operand goes global -> registers directly: an MFMA k-step
+//                                         takes curves {kk, kk + 16}, so a lane needs 16 CONTIGUOUS floats of its row
+//   db       += dG_t                      per-thread registers, reduced over the 32 curves once at the end
+// dG never leaves the chip; the tape rows and the [h | x] rows of step t-1 are fetched while step t computes.
+template <int NTX, bool FIRST, int DIRS>
+__global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, int l, int G, float* dy_out_base,
+                                                           const float* dy_in_base)
+{
+    constexpr int H = 32, UPT = 4, SP = 33;
+    constexpr int MTX = FIRST ? 1 : DIRS;     // output tiles of dy (unused when FIRST)
+    constexpr int NT = 1 + NTX;               // column tiles of [h | x]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dGl = smem;                        // [4H][33]
+    float* red = dGl + 4 * H * SP;            // [4 waves][H][32]
+    float* red2 = red + 4 * H * 32;           // [4 waves][MTX * 32][32]
+    int* origs = reinterpret_cast<int*>(red2 + (FIRST ? 0 : 4 * MTX * 32 * 32));   // [32]
+    const SnnLayout& y = p.lay;
+    const int d = blockIdx.x / G, g = blockIdx.x - d * G;
+    const int ld = l * DIRS + d;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, cl = lane & 31, hf = lane >> 5;
+    const int c = tid & 31, jg = tid >> 5;
+    const bool last_layer = l == y.L - 1;
+    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    const int64_t ts = tape_step_floats(H);
+    const int64_t dy_dir = (int64_t)p.n_tiles * DIRS * p.max_T * H * 32;   // floats of one producer's dy block
+
+    float wT[16], aih[MTX][16];
+    {
+        const float* A = p.WT + p.wt_hh[ld] + (int64_t)(16 * w) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) wT[kk] = A[kk * 64];
+        if (!FIRST) {
+#pragma unroll
+            for (int mt = 0; mt < MTX; ++mt) {
+                const float* B = p.WT + p.wt_ih[ld] + ((int64_t)mt * 2 * H + 16 * w) * 64 + lane;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) aih[mt][kk] = B[kk * 64];
+            }
+        }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+    float db[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) db[i] = 0.0f;
+
+    for (int band = 0;; ++band) {
+        const int tile = band * G + ((band & 1) ? G - 1 - g : g);
+        if (band * G >= p.n_tiles) break;
+        if (tile >= p.n_tiles) continue;
+        const int T = __builtin_amdgcn_readfirstlane(p.tile_T[tile]);
+        const int len = p.len_sorted[tile * SNN_TILE + c];
+        const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+        const float* tape = p.tape + (int64_t)tile * p.tape_tile;
+        const float* tape_ld = tape + (int64_t)ld * p.max_T * ts;
+        const float* dfeat = p.dfeat + (int64_t)tile * y.F * 32;
+        const float* xtile = p.xp + p.tile_off[tile];
+        const float* dy_in = last_layer ? nullptr : dy_in_base + ((int64_t)tile * DIRS + d) * p.max_T * H * 32;
+        __syncthreads();                       // previous item done with LDS
+        if (tid < 32) origs[tid] = p.order[tile * SNN_TILE + tid];
+        __syncthreads();
+
+        float dc[UPT], dhr[UPT], dfm[UPT];
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int j = jg + 8 * i;
+            dc[i] = 0.0f;
+            dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
+            dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + j) * 32 + c] * inv_len : 0.0f;
+        }
+        float n_q[5][UPT], n_dy[UPT];
+        f32x4 n_xh[NT][4];
+        auto fetch = [&](int step) {
+            const int t = d == 0 ? step : T - 1 - step;
+            const int tp = d == 0 ? t - 1 : t + 1;
+            const float* tq = tape_ld + (int64_t)t * ts + c;
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int j = jg + 8 * i;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) n_q[q][i] = tq[(q * H + j) * 32];
+                float v = 0.0f;
+                if (dy_in) {
+                    const int64_t o = (int64_t)t * H * 32 + j * 32 + c;
+                    v = dy_in[o];
+                    if (DIRS == 2) v += dy_in[dy_dir + o];
+                }
+                n_dy[i] = v;
+            }
+            // [h_{prev} | x_t] rows of this lane's columns, curves 16 hf .. 16 hf + 15
+            {
+                const float* hp = tape_ld + (int64_t)tp * ts + 5 * H * 32 + cl * 32 + 16 * hf;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    n_xh[0][q] = step > 0 ? *reinterpret_cast<const f32x4*>(hp + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int nt = 1; nt < NT; ++nt) {
+                const int k = 32 * (nt - 1) + cl;
+                const float* src = nullptr;
+                if (FIRST) {
+                    if (k < y.Dp) src = xtile + ((int64_t)t * y.Dp + k) * 32 + 16 * hf;
+                } else if (k < DIRS * H) {
+                    const int dd = k / H, kk = k - dd * H;
+                    src = tape + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + 16 * hf;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = src ? *reinterpret_cast<const f32x4*>(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (masked && src) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = origs[16 * hf + 4 * q + e];
+                            if (o >= 0)
+                                v[e] = __fmul_rn(FIRST ? (k < y.D ? mask_in(p.mk, 0, p.n_curves, y.D, o, k) : 1.0f)
+                                                       : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
+                        }
+                    }
+                    n_xh[nt][q] = v;
+                }
+            }
+        };
+        if (T > 0) fetch(T - 1);
+
+        for (int sb = 0; sb < T; ++sb) {
+            const int step = T - 1 - sb;
+            const int t = d == 0 ? step : T - 1 - step;
+            const int tp = d == 0 ? t - 1 : t + 1;
+            const bool valid = t < len;
+            const bool prev_live = step > 0 && tp < len;
+            float q_[5][UPT], dyv[UPT];
+            f32x4 xh[NT][4];
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) q_[q][i] = n_q[q][i];
+                dyv[i] = n_dy[i];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xh[nt][q] = n_xh[nt][q];
+            if (step > 0) fetch(step - 1);     // n_q[4] is then c of the step this one started from
+            // ---- gate gradients of this thread's 4 units (curve c)
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int j = jg + 8 * i;
+                float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+                if (valid) {
+                    const float ig = q_[0][i], fg = q_[1][i], gg = q_[2][i], og = q_[3][i], cn = q_[4][i];
+                    float dh = dhr[i] + dyv[i];
+                    if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
+                    const float cp = prev_live ? n_q[4][i] : 0.0f;
+                    const float tc = snn_tanh(cn);
+                    const float dct = dc[i] + dh * og * (1.0f - tc * tc);
+                    dao = dh * tc * og * (1.0f - og);
+                    dai = dct * gg * ig * (1.0f - ig);
+                    daf = dct * cp * fg * (1.0f - fg);
+                    dag = dct * ig * (1.0f - gg * gg);
+                    dc[i] = dct * fg;
+                }
+                dGl[(0 * H + j) * SP + c] = dai;
+                dGl[(1 * H + j) * SP + c] = daf;
+                dGl[(2 * H + j) * SP + c] = dag;
+                dGl[(3 * H + j) * SP + c] = dao;
+                db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
+            }
+            __syncthreads();
+            // ---- dh_{prev} and dy of the layer below: K = this wave's 32 gate rows
+            {
+                f32x16 ah, ax[MTX];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    ah[i] = 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < MTX; ++mt) ax[mt][i] = 0.0f;
+                }
+                const float* b = dGl + (32 * w + hf) * SP + cl;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const float bv = b[2 * kk * SP];
+                    ah = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[kk], bv, ah, 0, 0, 0);
+                    if (!FIRST) {
+#pragma unroll
+                        for (int mt = 0; mt < MTX; ++mt) ax[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aih[mt][kk], bv, ax[mt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = (i & 3) + 8 * (i >> 2) + 4 * hf;
+                    red[(w * H + r) * 32 + cl] = ah[i];
+                    if (!FIRST) {
+#pragma unroll
+                        for (int mt = 0; mt < MTX; ++mt) red2[((w * MTX + mt) * 32 + r) * 32 + cl] = ax[mt][i];
+                    }
+                }
+            }
+            // ---- dW += dG_t [h_prev | x_t]^T : A = this wave's 32 gate rows, k-step kk = curves {kk, kk + 16}
+            {
+                const float* a = dGl + (32 * w + cl) * SP + 16 * hf;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const float av = a[kk];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[nt][kk >> 2][kk & 3], acc[nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
+#pragma unroll
+                for (int i = 0; i < UPT; ++i) {
+                    const int j = jg + 8 * i;
+                    dhr[i] = ((red[(0 * H + j) * 32 + c] + red[(1 * H + j) * 32 + c]) + red[(2 * H + j) * 32 + c]) + red[(3 * H + j) * 32 + c];
+                }
+            }
+            if (!FIRST) {
+                const int o = origs[c];
+#pragma unroll
+                for (int i = 0; i < MTX * 4; ++i) {
+                    const int f = jg + 8 * i, mt = f >> 5, r = f & 31;
+                    float s = ((red2[((0 * MTX + mt) * 32 + r) * 32 + c] + red2[((1 * MTX + mt) * 32 + r) * 32 + c]) +
+                               red2[((2 * MTX + mt) * 32 + r) * 32 + c]) + red2[((3 * MTX + mt) * 32 + r) * 32 + c];
+                    if (masked && o >= 0) s = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, f), s);
+                    const int dd = f / H, j = f - dd * H;
+                    dy_out_base[(int64_t)d * dy_dir + (((int64_t)tile * DIRS + dd) * p.max_T + t) * H * 32 + j * 32 + c] = s;
+                }
+            }
+        }
+    }
+
+    // ---- this workgroup's partial sums -> its slab (canonical layout, only the (layer, direction) slices it owns)
+    float* slab = p.slabs + (int64_t)blockIdx.x * y.P;
+    const int I = y.I[l];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int R = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
+            const float v = acc[nt][i];
+            if (nt == 0) {
+                const float m = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
+                slab[y.c_whh[ld] + (int64_t)R * H + cl] = m * v;
+            } else {
+                const int k = 32 * (nt - 1) + cl;
+                if (k < I) slab[y.c_wih[ld] + (int64_t)R * I + k] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = db[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (c == 0) {
+            const int R = (i >> 2) * H + jg + 8 * (i & 3);
+            slab[y.c_bih[ld] + R] = v;
+            slab[y.c_bhh[ld] + R] = v;
+        }
+    }
+}
+
+// dflat[i] (+)= sum over the G workgroups of the direction parameter i belongs to, fixed order
+__global__ void __launch_bounds__(256) stream_reduce_kernel(SnnLayout y, int G, const float* __restrict__ slabs,
+                                                           float* __restrict__ out, int accumulate)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= y.c_head_w) return;
+    int ld = 0;
+    const int nld = y.L * y.dirs;
+    while (ld + 1 < nld && i >= y.c_wih[ld + 1]) ++ld;
+    const int d = ld % y.dirs;
+    float s = accumulate ? out[i] : 0.0f;
+    const float* src = slabs + (int64_t)d * G * y.P + i;
+    for (int k = 0; k < G; ++k) s += src[(int64_t)k * y.P];
+    out[i] = s;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct Bwd2Geom { int n_chunks; int64_t wt_floats, dfeat_floats, dG_floats, dy_floats, slab_floats, total_bytes; };
 
@@ -498,6 +787,95 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, total / 2));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
+}
+
+// ---- streamed path, host side
+struct StreamGeom { int G; int64_t wt_floats, dfeat_floats, dy_floats, slab_floats, total_bytes; };
+typedef void (*bwd_stream_t)(const Bwd2Params, int, int, float*, const float*);
+
+bool snn_bwd_stream_supported(const SnnLayout& y) { return y.H == 32 && y.D <= SNN_MAX_D && y.Dp <= 96; }
+
+static int stream_geom(const SnnLayout& y, int n_tiles, int max_T, StreamGeom* g, int64_t* wt_hh, int64_t* wt_ih)
+{
+    Bwd2Geom b;
+    bwd2_geom(y, n_tiles, max_T, &b, wt_hh, wt_ih);
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev != cached_dev) {
+        HIP_CHECK(hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        cached_dev = dev;
+    }
+    g->G = std::max(1, std::min(n_tiles, cached_cus / y.dirs));      // one workgroup per CU, split over the directions
+    g->wt_floats = b.wt_floats;
+    g->dfeat_floats = b.dfeat_floats;
+    g->dy_floats = y.L > 1 ? (int64_t)y.dirs * b.dy_floats : 0;      // one block per producing direction
+    g->slab_floats = (int64_t)y.dirs * g->G * y.P;
+    g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + (y.L > 2 ? 2 : 1) * g->dy_floats + g->slab_floats) + 1024;
+    return SNN_OK;
+}
+
+int64_t snn_bwd_stream_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
+{
+    StreamGeom g;
+    int rc = stream_geom(y, n_tiles, max_T, &g, nullptr, nullptr);
+    return rc ? rc : g.total_bytes;
+}
+
+template <int DIRS>
+static bwd_stream_t stream_kernel(int ntx, bool first)
+{
+    if (first) return ntx == 1 ? bwd_stream_kernel<1, true, DIRS> : ntx == 2 ? bwd_stream_kernel<2, true, DIRS> : bwd_stream_kernel<3, true, DIRS>;
+    return bwd_stream_kernel<DIRS, false, DIRS>;
+}
+
+int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
+                             const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles, int32_t max_T,
+                             const float* wk, const MaskP& mk, const float* tape, int64_t tape_tile, const float* dlogits,
+                             float* dflat, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    Bwd2Params p;
+    memset(&p, 0, sizeof(p));
+    StreamGeom g;
+    int rc = stream_geom(y, n_tiles, max_T, &g, p.wt_hh, p.wt_ih);
+    if (rc) return rc;
+    if (workspace_bytes < g.total_bytes) {
+        snn_set_error("snn_lstm_backward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.total_bytes);
+        return SNN_ERR_WORKSPACE;
+    }
+    p.lay = y;
+    p.xp = xp; p.len_sorted = len_sorted; p.order = order; p.tile_T = tile_T; p.tile_off = tile_off;
+    p.n_curves = n_curves; p.n_tiles = n_tiles; p.max_T = max_T; p.wk = wk; p.mk = mk;
+    p.tape = tape; p.tape_tile = tape_tile; p.dlogits = dlogits;
+    p.WT = (float*)workspace;
+    p.dfeat = p.WT + g.wt_floats;
+    float* dyA = p.dfeat + g.dfeat_floats;
+    float* dyB = y.L > 2 ? dyA + g.dy_floats : dyA;
+    p.slabs = dyA + (y.L > 2 ? 2 : 1) * g.dy_floats;
+    p.dflat = dflat;
+    p.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ld = y.L * y.dirs;
+    hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p);
+    HIP_CHECK(hipGetLastError());
+    for (int l = y.L - 1; l >= 0; --l) {
+        const bool first = l == 0;
+        const int ntx = first ? (y.Dp + 31) / 32 : y.dirs;
+        bwd_stream_t fn = y.dirs == 2 ? stream_kernel<2>(ntx, first) : stream_kernel<1>(ntx, first);
+        const int mtx = first ? 0 : y.dirs;
+        const size_t lds = sizeof(float) * ((size_t)4 * 32 * 33 + 4 * 32 * 32 + (size_t)4 * mtx * 32 * 32 + 32);
+        HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        float* dy_out = (l & 1) ? dyA : dyB;          // written by layer l for layer l - 1
+        const float* dy_in = (l & 1) ? dyB : dyA;     // written by layer l + 1
+        hipLaunchKernelGGL(fn, dim3(y.dirs * g.G), dim3(256), lds, st, p, l, g.G, dy_out, dy_in);
+        HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y, g.G, p.slabs,
+                       p.dflat, p.accumulate);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
 }
 
 bool snn_bwd_big_supported(const SnnLayout& y) { return (y.H == 32 || y.H == 64 || y.H == 128) && y.D <= SNN_MAX_D; }

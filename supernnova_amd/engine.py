@@ -150,16 +150,19 @@ def pack_x(cfg, plan, x, time_major=True):
     return xp
 
 
-def pack_ragged(cfg, plan, rows, curve_off):
+def pack_ragged(cfg, plan, rows, curve_off, shared_rows=False):
     """rows: concatenated (sum(len), D) fp32 on the GPU; curve_off: int64 (N,) float offset of each
-    curve's first row (device).  No padded copy is ever materialised."""
+    curve's first row (device).  No padded copy is ever materialised.
+    shared_rows: the plan's curves are VIEWS into `rows` that may overlap (prefixes of the same light curve for
+    early classification): rows then need not hold sum(lengths) rows; the caller guarantees that every view
+    [curve_off, curve_off + length * D) lies inside `rows`."""
     _require_cuda(rows, "rows")
     D = cfg.input_size
     if rows.dim() != 2 or rows.size(1) != D:
         raise L.SnnError(f"rows must be (sum(len), {D}), got {tuple(rows.shape)}")
     if curve_off.dtype != torch.int64 or curve_off.numel() != plan.n_curves or not curve_off.is_cuda:
         raise L.SnnError("curve_off must be a device int64 tensor with one entry per curve")
-    if rows.size(0) != int(plan.lengths.astype(np.int64).sum()):
+    if not shared_rows and rows.size(0) != int(plan.lengths.astype(np.int64).sum()):
         raise L.SnnError("rows does not hold sum(lengths) rows")
     n_xp = plan.packed_floats(cfg)
     xp = torch.empty(n_xp, dtype=torch.float32, device=rows.device)
@@ -256,7 +259,19 @@ class Masks:
                           *(None if m is None else m.data_ptr() for m in (self.m_in, self.m_whh, self.m_mid, self.m_out)))
 
 
+# Forward / backward workspaces, one per (device, stream) in use, grown on demand and kept for re-use: the forward's is
+# 256 B + grid x layer-output slab (H=32, T=40: 768 workgroups x 655 KB = 503 MB; H=128, T=300: 256 x 29 MB = 7.5 GB),
+# the split backward's 64 KB per tile-step (4 GB at 65 536 curves).  release_workspaces() hands them back to torch's
+# allocator (e.g. between a T=300 job and a T=40 one, or when a side stream is retired: a recycled stream handle
+# would otherwise inherit the retired stream's buffer, which is harmless but keeps the memory).
 _workspaces = {}
+
+
+def release_workspaces(device=None):
+    """Drop the cached forward / backward workspaces (of `device`, or of every device)."""
+    for cache in (_workspaces, _bwd_workspaces):
+        for key in [k for k in cache if device is None or k[0] == torch.device(device)]:
+            del cache[key]
 
 
 def _workspace(cfg, max_T, device):
@@ -317,21 +332,6 @@ def lstm_forward(cfg, plan, xp, wk, n_samples, masks=None, want_logits=True, wan
     return logits, probs
 
 
-# ----------------------------------------------------------------------------- training
-def lstm_forward_train(cfg, plan, xp, wk, masks=None):
-    """Training forward of one weight set. Returns (logits (N,C) original order, tape)."""
-    _require_cuda(xp, "xp")
-    _require_cuda(wk, "wk")
-    dev = xp.device
-    if wk.numel() != cfg.PK:
-        raise L.SnnError("training forward takes exactly one weight set (PK floats)")
-    n_tape = L.check(L.load().snn_train_tape_floats(ctypes.byref(cfg.c), plan.n_tiles, plan.max_T),
-                     "snn_train_tape_floats")
-    tape = torch.empty(n_tape, dtype=torch.float32, device=dev)
-    logits = torch.empty((plan.n_curves, cfg.nb_classes), dtype=torch.float32, device=dev)
-    mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
-    ws = _workspace(cfg, plan.max_T, dev)
-    L.check(L.load().snn_lstm_forward_train(
 def last_forward_kernel():
     """Name + launch geometry of the forward kernel this thread dispatched last (snn_last_forward_kernel)."""
     return (L.load().snn_last_forward_kernel() or b"").decode()
@@ -364,6 +364,21 @@ def lstm_forward_noalloc(cfg, plan, xp, wk, n_samples, logits=None, probs=None, 
     return logits, probs
 
 
+# ----------------------------------------------------------------------------- training
+def lstm_forward_train(cfg, plan, xp, wk, masks=None):
+    """Training forward of one weight set. Returns (logits (N,C) original order, tape)."""
+    _require_cuda(xp, "xp")
+    _require_cuda(wk, "wk")
+    dev = xp.device
+    if wk.numel() != cfg.PK:
+        raise L.SnnError("training forward takes exactly one weight set (PK floats)")
+    n_tape = L.check(L.load().snn_train_tape_floats(ctypes.byref(cfg.c), plan.n_tiles, plan.max_T),
+                     "snn_train_tape_floats")
+    tape = torch.empty(n_tape, dtype=torch.float32, device=dev)
+    logits = torch.empty((plan.n_curves, cfg.nb_classes), dtype=torch.float32, device=dev)
+    mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
+    ws = _workspace(cfg, plan.max_T, dev)
+    L.check(L.load().snn_lstm_forward_train(
         ctypes.byref(cfg.c), _ptr(xp), _ptr(plan.d_len_sorted), _ptr(plan.d_order), _ptr(plan.d_tile_T),
         _ptr(plan.d_tile_off), plan.n_curves, plan.n_tiles, plan.max_T, _ptr(wk),
         ctypes.byref(mc) if mc is not None else None, _ptr(logits), _ptr(tape), tape.numel(),
@@ -437,11 +452,14 @@ def ce_loss_grad(logits, target, grad_scale=None):
     N, C = logits.shape
     if target.dtype != torch.int64 or not target.is_cuda or target.numel() != N:
         raise L.SnnError("target must be a device int64 tensor with one entry per curve")
-    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    n_part = L.load().snn_ce_loss_partials(N)
+    # one allocation: the loss scalar, then (8-byte aligned) the fp64 per-workgroup partials large batches need
+    buf = torch.empty(2 + 2 * n_part, dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
     L.check(L.load().snn_ce_loss_grad(N, C, _ptr(logits), _ptr(target), 1.0 / N if grad_scale is None else grad_scale,
-                                      _ptr(loss), _ptr(dlogits), _stream()), "snn_ce_loss_grad")
-    return loss[0], dlogits
+                                      _ptr(buf), _ptr(dlogits), _ptr(buf[2:]) if n_part else None, _stream()),
+            "snn_ce_loss_grad")
+    return buf[0], dlogits
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,

@@ -308,6 +308,8 @@ class _HipRNN(nn.Module):
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
         cfg = self.infer_cfg(masks is not None)
         plan = E.Plan(cfg, lengths, padded.device)
+        if callable(masks):          # masks whose shape depends on the plan (per-step between-layer dropout)
+            masks = masks(plan)
         xp = E.pack_x(cfg, plan, padded)
         return E.lstm_forward(cfg, plan, xp, wk, n_samples, masks=masks, want_logits=True,
                               want_probs=want_probs, sample_major=True), plan
@@ -341,6 +343,10 @@ class VanillaRNN(_HipRNN):
             fn = (lambda plan: masks) if masks is not None else self._masks
             logits, _ = self._train_forward(x, fn)
             return logits
+        if masks is None and self.training and self.dropout > 0:
+            # train mode under torch.no_grad(): the reference still applies nn.LSTM's and nn.Dropout's dropout
+            # (vanilla_rnn.py:26-33) -- grad mode only decides whether a tape is kept, not whether masks are drawn
+            masks = self._masks
         wk = E.prepare_weights(self.infer_cfg(masks is not None), self._flat("w"))
         (logits, _), _ = self._launch(x, wk, 1, masks)
         return logits[0]

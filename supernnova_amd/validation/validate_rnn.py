@@ -57,6 +57,10 @@ def construct_predict_dict(n_elements, n_samples, nb_classes, MFE=False):
 
 def ragged_to_device(curves, device):
     """list of (len_i, D) float32 arrays -> (rows (sum len, D) on device, curve_off int64 device, lengths)."""
+    rl = getattr(curves, "rows", None)
+    if rl is not None and len(curves) == len(curves.lengths):       # tu.RaggedList: already concatenated
+        return (torch.from_numpy(rl).to(device), torch.from_numpy(np.asarray(curves.curve_off, np.int64)).to(device),
+                curves.lengths)
     lengths = np.fromiter((c.shape[0] for c in curves), dtype=np.int32, count=len(curves))
     rows = torch.from_numpy(np.concatenate(curves, axis=0).astype(np.float32, copy=False)).to(device)
     D = rows.size(1)
@@ -86,6 +90,47 @@ def predict_mc(rnn, curves, n_samples, mean_field_inference=False, lengths=None,
     return probs
 
 
+def predict_mc_prefixes(rnn, curves, cuts, n_samples, mean_field_inference=False, device=None):
+    """Early classification in ONE launch: every (light curve k, prefix length cuts[v][k]) pair is a curve of its own
+    for the kernel -- a view of the first cuts[v][k] rows of curve k (no row is copied: the views share `rows`), so
+    the full curves and the 7 PEAKMJD-offset slices of validate_rnn.py:337-374 are one plan, one pack, one weight
+    draw and one persistent launch instead of 8.  (Only layer 0's forward direction could be shared between the
+    prefixes of a curve -- every other (layer, direction) sees the cut through the reverse pass -- so the prefixes run
+    as independent work items.)  The S weight draws / W_hh row masks are shared by all prefixes of the launch; the
+    reference draws anew for every forward, which leaves each key's statistics unchanged.
+
+    curves: list of (len_k, D) arrays; cuts: list of int arrays (N,), entries < 1 = "slice empty, no prediction".
+    Returns a list of (idx, probs (len(idx), S, C) device tensor) per entry of `cuts`, idx = curves with a slice."""
+    device = device or next(rnn.parameters()).device
+    rows, curve_off, lengths = ragged_to_device(curves, device)
+    D = rows.size(1)
+    off_host = np.zeros(len(curves), np.int64)
+    np.cumsum(lengths[:-1].astype(np.int64) * D, out=off_host[1:])
+    idxs, v_off, v_len = [], [], []
+    for c in cuts:
+        c = np.asarray(c)
+        if (c > lengths).any():
+            raise ValueError("a prefix length exceeds its light curve")
+        inb = np.where(c >= 1)[0]
+        idxs.append(inb)
+        v_off.append(off_host[inb])
+        v_len.append(c[inb].astype(np.int32))
+    all_len = np.concatenate(v_len)
+    if all_len.size == 0:
+        return [(i, torch.empty((0, n_samples, rnn.cfg.nb_classes), device=device)) for i in idxs]
+    wk, masks = rnn.mc_weights(n_samples, all_len.size, device, mean_field_inference)
+    cfg = rnn.infer_cfg(masks is not None)
+    plan = E.Plan(cfg, all_len, device)
+    xp = E.pack_ragged(cfg, plan, rows, torch.from_numpy(np.concatenate(v_off)).to(device), shared_rows=True)
+    _, probs = E.lstm_forward(cfg, plan, xp, wk, n_samples, masks=masks, want_logits=False, want_probs=True,
+                              sample_major=False)
+    out, a = [], 0
+    for inb in idxs:
+        out.append((inb, probs[a:a + len(inb)]))
+        a += len(inb)
+    return out
+
+
 def aggregate(probs):
     """Per-curve median and std over the S samples: the device-side equivalent of
     get_aggregated_dataframe's groupby(SNID).median()/.std() (validate_rnn.py:163-172;
@@ -96,10 +141,17 @@ def aggregate(probs):
     return med, std
 
 
-def get_predictions_mc(settings, rnn, list_data, peak_mjds=None, times=None):
+def get_predictions_mc(settings, rnn, list_data, peak_mjds=None, times=None, batch_size=None):
     """The MC part of get_predictions' _populate_predict_dict (validate_rnn.py:292-394) on in-memory
     data: fills "all", the PEAKMJD offsets (when peak_mjds/times are given) and the OOD variants,
-    for S = settings.num_inference_samples draws, plus the MFE dict.  Returns (d_pred, d_pred_MFE)."""
+    for S = settings.num_inference_samples draws, plus the MFE dict.  Returns (d_pred, d_pred_MFE).
+
+    Batching.  The reference walks mini-batches of settings.batch_size, and every forward of a mini-batch draws new
+    weights / masks.  In sampled mode (rnn.draws == "philox") all curves go through ONE launch per variant (the
+    statistics are the same, the launch count is not).  In parity mode (rnn.draws == "host") -- or when `batch_size`
+    is given -- the reference's mini-batches are kept, each variant of each mini-batch is one launch of S draws made
+    with the reference's torch calls in the reference's order, and numpy's global RNG is consumed by the OOD
+    transforms in the reference's order: seeded like a reference run, the dict replays that run."""
     settings.random_length = False
     settings.random_redshift = False
     S = 1 if settings.model == "vanilla" else settings.num_inference_samples
@@ -107,29 +159,63 @@ def get_predictions_mc(settings, rnn, list_data, peak_mjds=None, times=None):
     rnn.eval()
     targets = np.array([d[1] for d in list_data], np.int64)
     snids = np.array([str(d[2]) if len(d) > 2 else str(i) for i, d in enumerate(list_data)])
+    if batch_size is None and getattr(rnn, "draws", "philox") == "host":
+        batch_size = settings.batch_size
+    if batch_size is None:
+        batches = [np.arange(N)]
+    else:
+        batches = np.array_split(np.arange(N), int(N / min(N, batch_size)))   # validate_rnn.py:285-287
 
     def run(curves, n_samples, mfe):
         with torch.no_grad():
-            return predict_mc(rnn, curves, n_samples, mean_field_inference=mfe).cpu().numpy()
+            if batch_size is None:
+                return predict_mc(rnn, curves, n_samples, mean_field_inference=mfe).cpu().numpy()
+            # the reference draws its per-curve dropout masks for the length-SORTED mini-batch (get_data_batch,
+            # training_utils.py:449-453: np.argsort(list_len)[::-1]); host-drawn masks are indexed by position in the
+            # launch, so the launch takes the curves in that order and the rows are put back afterwards
+            idx_sort = np.argsort([c.shape[0] for c in curves])[::-1]
+            probs = predict_mc(rnn, [curves[k] for k in idx_sort], n_samples, mean_field_inference=mfe).cpu().numpy()
+            return probs[np.argsort(idx_sort)]
 
+    base = [x[0] for x in list_data]
     out = []
     for mfe, n_s in ((False, S), (True, 1)):
         d = construct_predict_dict(N, n_s, C, MFE=mfe)
         d["target"][:] = targets[:, None]
         d["SNID"][:] = snids[:, None]
-        base = [x[0] for x in list_data]
-        d["all"][:] = run(base, n_s, mfe)
-        if not mfe and peak_mjds is not None and times is not None:
-            for off, sfx in zip(OFFSETS_VAL, OFFSETS_STR):
-                cut = np.array([find_idx(times[k], peak_mjds[k] + off) for k in range(N)])
-                inb = np.where(cut >= 1)[0]
-                d[f"PEAKMJD{sfx}"][:] = np.nan        # empty slices: no prediction (validate_rnn.py:372-374)
-                if len(inb):
-                    d[f"PEAKMJD{sfx}"][inb] = run([base[k][: cut[k]] for k in inb], n_s, mfe)
-        for ood in ["random", "shuffle", "reverse", "sin"]:   # reference order (validate_rnn.py:380)
-            if ood in ("random", "sin") and not hasattr(settings, "idx_flux"):
-                continue
-            d[f"all_{ood}"][:] = run([tu._ood(x, ood, settings) for x in base], n_s, mfe)
+        if batch_size is None and not mfe and peak_mjds is not None and times is not None:
+            # sampled mode: full curves + the 7 early-classification slices in one launch, the 4 OOD variants in another
+            cuts = [np.array([len(c) for c in base])]
+            for off in OFFSETS_VAL:
+                cuts.append(np.array([find_idx(times[k], peak_mjds[k] + off) for k in range(N)]))
+            with torch.no_grad():
+                res = predict_mc_prefixes(rnn, base, cuts, n_s, mean_field_inference=mfe)
+            for key, (inb, pr) in zip(["all"] + [f"PEAKMJD{sfx}" for sfx in OFFSETS_STR], res):
+                if len(inb) or key == "all":
+                    if key != "all":
+                        d[key][:] = np.nan
+                    d[key][inb] = pr.cpu().numpy()
+            oods = [o for o in ["random", "shuffle", "reverse", "sin"] if o in ("shuffle", "reverse") or hasattr(settings, "idx_flux")]
+            if oods:
+                both = [tu._ood(x, ood, settings) for ood in oods for x in base]
+                pr = run(both, n_s, mfe)
+                for j, ood in enumerate(oods):
+                    d[f"all_{ood}"][:] = pr[j * N:(j + 1) * N]
+            out.append(d)
+            continue
+        for idxs in batches:
+            d["all"][idxs] = run([base[k] for k in idxs], n_s, mfe)
+            if not mfe and peak_mjds is not None and times is not None:
+                for off, sfx in zip(OFFSETS_VAL, OFFSETS_STR):
+                    cut = np.array([find_idx(times[k], peak_mjds[k] + off) for k in idxs])
+                    inb = np.where(cut >= 1)[0]
+                    if len(inb):     # (a mini-batch whose slices are all empty is left untouched, as the reference's)
+                        d[f"PEAKMJD{sfx}"][idxs[cut < 1]] = np.nan    # empty slices: no prediction (validate_rnn.py:372-374)
+                        d[f"PEAKMJD{sfx}"][idxs[inb]] = run([base[idxs[j]][: cut[j]] for j in inb], n_s, mfe)
+            for ood in ["random", "shuffle", "reverse", "sin"]:   # reference order (validate_rnn.py:380)
+                if ood in ("random", "sin") and not hasattr(settings, "idx_flux"):
+                    continue
+                d[f"all_{ood}"][idxs] = run([tu._ood(base[k], ood, settings) for k in idxs], n_s, mfe)
         out.append(d)
     return tuple(out)
 
@@ -177,27 +263,39 @@ def get_aggregated_dataframe(pred_df):
 
 
 def get_predictions(settings, model_file=None, list_data=None, peak_mjds=None, times=None, rnn=None):
-    """The RNN branch of validate_rnn.get_predictions (:229-442): load the state dict, run the MC and the
-    mean-field passes, write `PRED_<model>.pickle` (one row per curve and sample) and, for the variational and
-    Bayesian models, `PRED_<model>_aggregated.pickle`; returns the list of prediction files.
-    `list_data` is the test list tu.load_HDF5(settings, test=True) would return (HDF5 is out of scope here);
-    PEAKMJD offsets are filled when `peak_mjds` / `times` (per-curve arrays of observation times) are given.
-    The state dict is read with weights_only=True."""
+    """The RNN branch of validate_rnn.get_predictions (:229-442), reference signature `(settings, model_file=None)`:
+    load the test list from `settings.processed_dir/database.h5` (tu.load_HDF5) with the peak dates of
+    du.load_HDF5_SNinfo, load the state dict (weights_only), run the MC and the mean-field passes, write
+    `PRED_<model>.pickle` (one row per curve and sample) and, for the variational and Bayesian models,
+    `PRED_<model>_aggregated.pickle`; returns the list of prediction files.  Output directory as the reference:
+    `models_dir/<name>` without a model file, `dump_dir/models/<name>` with one (:253-273).
+    In-memory callers may pass `list_data` (the list tu.load_HDF5(settings, test=True) returns) and `peak_mjds` /
+    `times` themselves, and a loaded `rnn`."""
     import os
+    name = settings.pytorch_model_name
     if list_data is None:
-        raise ValueError("supernnova_amd.validation.validate_rnn.get_predictions takes the test list of "
-                         "tu.load_HDF5 as `list_data`: the HDF5 reader is not part of this package")
+        from ..utils import data_utils as du
+        list_data = tu.load_HDF5(settings, test=True)
+        info = du.load_HDF5_SNinfo(settings).set_index("SNID")
+        peak_mjds = info.loc[[d[2] for d in list_data]]["PEAKMJDNORM"].values
+        col = settings.d_feat_to_idx["delta_time"]
+        times = [np.cumsum(d[3][:, col]) for d in list_data]            # validate_rnn.py:303-308
+    if model_file is None and rnn is None:
+        dump_dir = getattr(settings, "rnn_dir", None) or f"{settings.models_dir}/{name}"
+        model_file = os.path.join(str(dump_dir), f"{name}.pt")
+    elif getattr(settings, "dump_dir", None) and model_file is not None and getattr(settings, "models_dir", None):
+        dump_dir = f"{settings.dump_dir}/models/{name}"
+    else:
+        dump_dir = getattr(settings, "dump_dir", None) or os.path.dirname(os.path.abspath(model_file or str(settings.rnn_dir) + "/x"))
+    os.makedirs(str(dump_dir), exist_ok=True)
     if rnn is None:
         rnn = tu.get_model(settings, list_data[0][0].shape[1])
-        if model_file is None:
-            model_file = os.path.join(str(settings.rnn_dir), f"{settings.pytorch_model_name}.pt")
         rnn.load_state_dict(torch.load(model_file, map_location="cpu", weights_only=True))
         rnn.to(getattr(settings, "device", "cuda"))
     rnn.eval()
-    dump_dir = getattr(settings, "dump_dir", None) or os.path.dirname(os.path.abspath(model_file or str(settings.rnn_dir) + "/x"))
     d_pred, d_pred_mfe = get_predictions_mc(settings, rnn, list_data, peak_mjds, times)
     df = flatten_to_dataframe(d_pred)
-    pred_file = os.path.join(dump_dir, f"PRED_{settings.pytorch_model_name}.pickle")
+    pred_file = os.path.join(str(dump_dir), f"PRED_{name}.pickle")
     df.to_pickle(pred_file, protocol=4)
     if settings.model in ("variational", "bayesian"):
         get_aggregated_dataframe(df).to_pickle(pred_file.replace(".pickle", "_aggregated.pickle"), protocol=4)

@@ -146,6 +146,37 @@ def test_sampled_mode_statistics(model, prec):
         assert rel_err(a, a32) < PROB_RTOL
 
 
+@pytest.mark.parametrize("model,prec", [("bayesian", "f32"), ("bayesian", "f16x2"), ("variational", "f32"),
+                                        ("variational", "f16x2")])
+def test_sampled_mode_gate(model, prec):
+    """The sampled-mode gate exactly as SURVEY 8d writes it: 10 000 curves, S = 50 Philox draws each, against the
+    reference's own S = 50 run A of fixture g5_gate_<model> (mini-batches of 5 curves share a weight draw / W_hh row
+    mask on both sides, every mini-batch is a launch with a fresh seed): >= 99.9 % of curves within
+    4*sqrt(2)*std_ref/sqrt(S), pooled bias < 1e-3, pooled predictive std within +-10 %, KS test of the standardised
+    differences against t(S-1) p > 0.01, and a two-sample KS against the reference's own run B vs A p > 0.01."""
+    from util import make_curves, sampled_gate, assert_sampled_gate
+    from supernnova_amd.validation import validate_rnn as vr
+    g = load_golden(f"g5_gate_{model}")
+    N, G, T, S = int(g["n"]), int(g["group"]), int(g["T"]), int(g["S"])
+    x, lengths = make_curves(int(g["seed"]), N, T, 24)
+    rnn = _model(model, g["sd"], 24, dropout=float(g["dropout"]))
+    rnn.inference_precision = prec
+    torch.manual_seed(777)
+    xd = torch.from_numpy(x).to(DEV)
+    out = []
+    with torch.no_grad():
+        for b0 in range(0, N, G):
+            idx = np.arange(b0, b0 + G)
+            rows = torch.cat([xd[: lengths[b], b] for b in idx])
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(lengths[idx].astype(np.int64))[:-1]]) * 24).to(DEV)
+            out.append(vr.predict_mc(rnn, (rows, off, lengths[idx]), S))       # (G, S, 2), one fresh seed per launch
+    probs = torch.cat(out).double()
+    mean, std = probs.mean(1).cpu().numpy(), probs.std(1, unbiased=True).cpu().numpy()
+    res = sampled_gate(mean, std, g["mean"][0], g["std"][0], S, G, mean_ref2=g["mean"][1])
+    print(model, prec, res)
+    assert_sampled_gate(res)
+
+
 @pytest.mark.parametrize("fast", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("model", ["vanilla", "bayesian"])
 def test_inference_precision_through_the_module_api(model, fast):
@@ -194,3 +225,22 @@ def test_vanilla_module_gru_rnn(cell, pool, kw, D):
     rnn.train()
     with pytest.raises(L.SnnError, match="inference kernels only"):
         rnn(_packed(g))
+
+
+def test_vanilla_train_mode_without_grad_still_applies_dropout():
+    """dropout is decided by module.training alone (vanilla_rnn.py:26-33: nn.LSTM(dropout=p) and nn.Dropout
+    act in train mode whatever the grad mode); torch.no_grad() only drops the tape.  Same seed -> same Philox masks ->
+    the no-grad forward equals the grad-enabled one, and both differ from eval mode."""
+    g = load_golden("g1_vanilla_mean")
+    rnn = _model("vanilla", g["sd"], 24, dropout=0.3)
+    x = _packed(g)
+    with torch.no_grad():
+        ev = rnn(x).cpu().numpy()
+    rnn.train()
+    torch.manual_seed(11)
+    with_grad = rnn(x).detach().cpu().numpy()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        no_grad = rnn(x).cpu().numpy()
+    assert np.array_equal(with_grad, no_grad)
+    assert np.abs(no_grad - ev).max() > 1e-3

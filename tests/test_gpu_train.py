@@ -364,3 +364,102 @@ def test_data_parallel_gradient_equals_full_batch_gradient(model):
     parts = [grads(*D.shard_range(B, r, 2)) for r in range(2)]
     mean = 0.5 * (parts[0] + parts[1])
     assert float((mean - full).abs().max()) < 2e-6 * max(1.0, float(full.abs().max()))
+
+
+def test_ce_loss_rejects_out_of_range_label_loudly():
+    """nn.CrossEntropyLoss raises on a label outside [0, C); the kernel reads nothing out of bounds, makes the loss NaN and
+    zeroes that curve's gradient row (the other rows are those of the valid curves)."""
+    from supernnova_amd import engine as E
+    g = np.random.default_rng(5)
+    for N in (7, 3000):          # one-workgroup path and the partials path
+        logits = _t(g.standard_normal((N, 3)))
+        target = torch.from_numpy(g.integers(0, 3, N)).to(DEV)
+        good_loss, good = E.ce_loss_grad(logits, target)
+        bad_t = target.clone()
+        bad_t[N // 2] = 3
+        bad_t[0] = -1
+        loss, d = E.ce_loss_grad(logits, bad_t)
+        assert bool(torch.isnan(loss)) and bool(torch.isfinite(good_loss))
+        assert float(d[N // 2].abs().max()) == 0.0 and float(d[0].abs().max()) == 0.0
+        keep = torch.ones(N, dtype=torch.bool, device=DEV)
+        keep[N // 2] = keep[0] = False
+        assert torch.equal(d[keep], good[keep])
+
+
+def test_ce_loss_calls_on_two_streams_do_not_share_state():
+    """The partial sums live in the caller's scratch (no library-global state): two large-batch calls enqueued on two
+    streams give the losses of the same calls made one after the other."""
+    from supernnova_amd import engine as E
+    g = np.random.default_rng(6)
+    a = (_t(g.standard_normal((50000, 2))), torch.from_numpy(g.integers(0, 2, 50000)).to(DEV))
+    b = (_t(g.standard_normal((70000, 2)) * 3), torch.from_numpy(g.integers(0, 2, 70000)).to(DEV))
+    ref = [float(E.ce_loss_grad(*a)[0]), float(E.ce_loss_grad(*b)[0])]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    out = []
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            la = E.ce_loss_grad(*a)[0]
+        with torch.cuda.stream(s2):
+            lb = E.ce_loss_grad(*b)[0]
+        out.append((la, lb))
+    torch.cuda.synchronize()
+    for la, lb in out:
+        assert [float(la), float(lb)] == ref
+    E.release_workspaces()
+    assert not E._workspaces and not E._bwd_workspaces
+
+
+def test_pack_x_refuses_a_buffer_smaller_than_the_plan():
+    import ctypes
+    from supernnova_amd import engine as E, _lib as L
+    cfg = E.Config(24, 32, 2, True, 2, "mean")
+    lengths = np.full(100, 9, np.int32)
+    plan = E.Plan(cfg, lengths, DEV)
+    x = torch.zeros((9, 100, 24), device=DEV)
+    xp = torch.full((plan.packed_floats(cfg),), 7.0, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    call = lambda n_words: L.load().snn_pack_x(
+        ctypes.byref(cfg.c), P(x), 100 * 24, 24, None, P(plan.d_order), P(plan.d_len_sorted), P(plan.d_tile_T),
+        P(plan.d_tile_off), plan.n_tiles, n_words, P(xp), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert call(plan.n_tiles * 24 * 32 - 1) == -1      # below one step per tile: SNN_ERR_ARG
+    # enough for three of the four tiles: the fourth is left untouched, nothing is written past the stated size
+    three = int(plan.tile_off[3])
+    assert call(three) == 0
+    torch.cuda.synchronize()
+    assert float(xp[:three].abs().max()) == 0.0 and bool((xp[three:] == 7.0).all())
+
+
+@pytest.mark.parametrize("D,dirs,pool,C,masked", [(24, 2, "mean", 2, False), (48, 2, "standard", 5, True),
+                                                  (78, 1, "mean", 3, False), (26, 1, "standard", 2, True)])
+def test_streamed_backward_equals_split_backward(D, dirs, pool, C, masked):
+    """H = 32 runs the streamed backward (bwd_stream_kernel: one pass per (layer, direction), dG in LDS, dW in
+    registers over a stripe of tiles); the round-1 split path (bwd_rec / bwd_dx / bwd_dw through HBM) stays selectable
+    with SNN_BWD_PATH=split.  Same tape, same dlogits: the two give the same gradient up to summation order, for more
+    tiles than workgroups (stripes of several tiles, serpentine) and for a handful of tiles."""
+    import os
+    from supernnova_amd import engine as E
+    from util import make_curves
+    cfg = E.Config(D, 32, 2, dirs == 2, C, pool)
+    w = np.random.default_rng(4).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    wk = E.prepare_weights(cfg, _t(w))
+    for n, T in ((9000, 30), (70, 12)):
+        x, lengths = make_curves(33, n, T, D, min_len=1)
+        plan = E.Plan(cfg, lengths, DEV)
+        xp = E.pack_x(cfg, plan, _t(x))
+        mk = (lambda: E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=77, mid_T=1)) if masked else (lambda: None)
+        logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
+        dlog = _t(np.random.default_rng(5).standard_normal((n, C)) / n)
+        out = {}
+        for path in ("stream", "split"):
+            os.environ["SNN_BWD_PATH"] = path
+            try:
+                out[path] = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk()).cpu().numpy()
+            finally:
+                os.environ.pop("SNN_BWD_PATH")
+        scale = np.abs(out["split"]).max()
+        assert scale > 0
+        np.testing.assert_allclose(out["stream"], out["split"], rtol=0, atol=2e-5 * scale)
+        # deterministic: a second run of the streamed path is bit-identical
+        again = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk()).cpu().numpy()
+        assert np.array_equal(again, out["stream"])
