@@ -10,11 +10,11 @@ for d in sys.argv[1:]:
     n = defaultdict(int)
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:40]
+            k = r["Kernel_Name"][:60]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[(k, r["Counter_Name"])] += 1
     for k, cs in acc.items():
-        if "lstm" not in k and "pack" not in k:
+        if not any(t in k for t in ("lstm", "pack", "bwd", "head_", "reduce", "bbb", "adam", "ce_loss")):
             continue
         print(d, k)
         for c, v in sorted(cs.items()):

@@ -65,11 +65,15 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
                              const int32_t* tile_T, const int64_t* tile_off, int32_t n_curves, int32_t n_tiles, int32_t max_T,
                              const float* wk, const MaskP& mk, const float* tape, int64_t tape_tile, const float* dlogits,
                              float* dflat, int32_t accumulate, void* workspace, int64_t workspace_bytes, void* stream);
-static bool use_stream_path(const SnnLayout& y)
+static bool use_stream_path(const SnnLayout& y, int n_tiles)
 {
     const char* force = getenv("SNN_BWD_PATH");     // read per call: the tests switch paths inside one process
     if (force && (force[0] == 'f' || (force[0] == 's' && force[1] == 'p'))) return false;
-    return snn_bwd_stream_supported(y);
+    if (!snn_bwd_stream_supported(y)) return false;
+    if (force && force[0] == 's' && force[1] == 't') return true;
+    // a handful of tiles is a latency chain either way, and the split path's chain (recurrent product only) is the
+    // shorter one: batch 128 backward 0.23 ms split / 0.43 ms streamed; 8192: 1.00 / 0.79; 65536: 5.29 / 4.42
+    return n_tiles * y.dirs >= 128;
 }
 // H = 64, 128: recurrent kernel + deferred GEMMs (snn_train_big.hip)
 bool snn_bwd_big_supported(const SnnLayout& y);
@@ -96,7 +100,7 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     if ((rc = snn_lstm_only(y, "snn_lstm_backward_workspace_bytes"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
     const BwdEntry* fused = find_bwd(y);
-    if (use_stream_path(y)) return snn_bwd_stream_workspace_bytes(y, n_tiles, max_T);
+    if (use_stream_path(y, n_tiles)) return snn_bwd_stream_workspace_bytes(y, n_tiles, max_T);
     if (use_split_path(y, fused, n_tiles)) {
         if (snn_bwd_big_supported(y)) return snn_bwd_big_workspace_bytes(y, n_tiles, max_T);
         snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs);
@@ -128,7 +132,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     }
     const int64_t tape_tile = tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F);
     if (tape_floats < tape_tile * n_tiles) { snn_set_error("snn_lstm_backward: tape too small"); return SNN_ERR_ARG; }
-    if (use_stream_path(y)) {
+    if (use_stream_path(y, n_tiles)) {
         MaskP mk;
         rc = snn_masks_to_device(masks, max_T, &mk);
         if (rc) return rc;

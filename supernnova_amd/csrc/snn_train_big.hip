@@ -479,57 +479,67 @@ __global__ void __launch_bounds__(256) chunk_reduce_kernel(int64_t n, int64_t P,
 // twice (bwd_dx, bwd_dw): at 65 536 curves that is 7 of the 13.5 GB the backward moves, and bwd_rec alone is HBM-bound.
 // Here a workgroup owns a direction and a fixed stripe of tiles (serpentine over the length-sorted tiles, so the
 // stripes carry equal work and the summation order is fixed), walks each tile's tape backwards and keeps dG_t in LDS:
-//   dh_{t-1}  = W_hh^T dG_t               16 MFMAs per wave (wave w owns gate rows 32w..32w+31 = its K range)
-//   dy_below  = W_ih^T dG_t  (layer > 0)  16 x DIRS MFMAs per wave, same B operand reads as the line above
-//   dW       += dG_t [h_{t-1} | x_t]^T    16 x (1 + NTX) MFMAs per wave, accumulators stay in registers for the whole
-//                                         stripe; the [h | x] operand goes global -> registers directly: an MFMA k-step
-//                                         takes curves {kk, kk + 16}, so a lane needs 16 CONTIGUOUS floats of its row
+//   dh_{t-1}  = W_hh^T dG_t               16 MFMAs per step on each SIMD (K split over the 4 SIMDs: gate rows 32s..32s+31)
+//   dy_below  = W_ih^T dG_t  (layer > 0)  16 x DIRS
+//   dW       += dG_t [h_{t-1} | x_t]^T    16 x (1 + NTX); accumulators stay in registers for the whole stripe; the
+//                                         [h | x] operand goes global -> registers directly: an MFMA k-step takes curves
+//                                         {kk, kk + 16}, so a lane needs 16 CONTIGUOUS floats of its row
 //   db       += dG_t                      per-thread registers, reduced over the 32 curves once at the end
-// dG never leaves the chip; the tape rows and the [h | x] rows of step t-1 are fetched while step t computes.
-template <int NTX, bool FIRST, int DIRS>
-__global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, int l, int G, float* dy_out_base,
-                                                           const float* dy_in_base)
+// dG never leaves the chip.  8 waves: waves s and s + 4 share SIMD s and split its products by ROLE -- role 0 takes
+// dh and the first half of the dW column tiles, role 1 dy_below and the rest -- so each wave stays under 256
+// registers and two waves per SIMD cover each other's LDS / memory waits (with 4 waves of 455 registers every wait of
+// the step was exposed: 13.8 k cycles per step against 6.1 k cycles of MFMA).  Everything a step reads from HBM is
+// fetched one step ahead by loads that are unconditional (clamped addresses, values discarded by selects), so they
+// issue back to back and nothing waits for a load in the step that issued it.
+#ifndef SNN_STREAM_OCC
+#define SNN_STREAM_OCC 1
+#endif
+template <int NTX, bool FIRST, int DIRS, bool MASKED, int ROLE>
+__device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int G, float* dy_out_base,
+                                                const float* dy_in_base, float* smem)
 {
-    constexpr int H = 32, UPT = 4, SP = 33;
+    constexpr int H = 32, UPT = 2, SP = 33;
     constexpr int MTX = FIRST ? 1 : DIRS;     // output tiles of dy (unused when FIRST)
     constexpr int NT = 1 + NTX;               // column tiles of [h | x]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT0 = (NT + 1) / 2;         // tiles [0, NT0) belong to role 0, [NT0, NT) to role 1
+    constexpr int T0 = ROLE == 0 ? 0 : NT0, MYNT = ROLE == 0 ? NT0 : NT - NT0;
+    constexpr bool DO_REC = ROLE == 0, DO_DX = ROLE == 1 && !FIRST;
     float* dGl = smem;                        // [4H][33]
-    float* red = dGl + 4 * H * SP;            // [4 waves][H][32]
-    float* red2 = red + 4 * H * 32;           // [4 waves][MTX * 32][32]
+    float* red = dGl + 4 * H * SP;            // [4 SIMDs][H][32]
+    float* red2 = red + 4 * H * 32;           // [4 SIMDs][MTX * 32][32]
     int* origs = reinterpret_cast<int*>(red2 + (FIRST ? 0 : 4 * MTX * 32 * 32));   // [32]
     const SnnLayout& y = p.lay;
     const int d = blockIdx.x / G, g = blockIdx.x - d * G;
     const int ld = l * DIRS + d;
-    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, cl = lane & 31, hf = lane >> 5;
-    const int c = tid & 31, jg = tid >> 5;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
+    const int c = tid & 31, jg = tid >> 5;    // element-wise stage: curve c, hidden units jg and jg + 16
     const bool last_layer = l == y.L - 1;
-    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    constexpr bool masked = MASKED;           // the un-masked instantiation carries no mask code
     const int64_t ts = tape_step_floats(H);
     const int64_t dy_dir = (int64_t)p.n_tiles * DIRS * p.max_T * H * 32;   // floats of one producer's dy block
 
-    float wT[16], aih[MTX][16];
-    {
+    float wT[DO_REC ? 16 : 1], aih[DO_DX ? MTX : 1][16];
+    if (DO_REC) {
         const float* A = p.WT + p.wt_hh[ld] + (int64_t)(16 * w) * 64 + lane;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) wT[kk] = A[kk * 64];
-        if (!FIRST) {
+    }
+    if (DO_DX) {
 #pragma unroll
-            for (int mt = 0; mt < MTX; ++mt) {
-                const float* B = p.WT + p.wt_ih[ld] + ((int64_t)mt * 2 * H + 16 * w) * 64 + lane;
+        for (int mt = 0; mt < MTX; ++mt) {
+            const float* B = p.WT + p.wt_ih[ld] + ((int64_t)mt * 2 * H + 16 * w) * 64 + lane;
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) aih[mt][kk] = B[kk * 64];
-            }
+            for (int kk = 0; kk < 16; ++kk) aih[mt][kk] = B[kk * 64];
         }
     }
-    f32x16 acc[NT];
+    f32x16 acc[MYNT > 0 ? MYNT : 1];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < MYNT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
-    float db[16];
+    float db[4 * UPT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) db[i] = 0.0f;
+    for (int i = 0; i < 4 * UPT; ++i) db[i] = 0.0f;
 
     for (int band = 0;; ++band) {
         const int tile = band * G + ((band & 1) ? G - 1 - g : g);
@@ -550,60 +560,64 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
         float dc[UPT], dhr[UPT], dfm[UPT];
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 8 * i;
+            const int j = jg + 16 * i;
             dc[i] = 0.0f;
             dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
             dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + j) * 32 + c] * inv_len : 0.0f;
         }
-        float n_q[5][UPT], n_dy[UPT];
-        f32x4 n_xh[NT][4];
+        // q 5 = c of the step before, fetched WITH the step (taken from the next fetch it would make every step wait for
+        // loads it has just issued); dy of both producing directions, added when consumed (an add at fetch time waits too)
+        float n_q[6][UPT], n_dy[DIRS][UPT];
+        f32x4 n_xh[MYNT > 0 ? MYNT : 1][4];
+        const float* dy0 = dy_in ? dy_in : tape_ld;          // last layer: any valid address, value unused
+        const bool has_dy = dy_in != nullptr;
         auto fetch = [&](int step) {
             const int t = d == 0 ? step : T - 1 - step;
-            const int tp = d == 0 ? t - 1 : t + 1;
+            const int tpc = step > 0 ? (d == 0 ? t - 1 : t + 1) : t;      // clamped: step 0 has no predecessor
             const float* tq = tape_ld + (int64_t)t * ts + c;
+            const float* tqp = tape_ld + (int64_t)tpc * ts + c;
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-                const int j = jg + 8 * i;
+                const int j = jg + 16 * i;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) n_q[q][i] = tq[(q * H + j) * 32];
-                float v = 0.0f;
-                if (dy_in) {
-                    const int64_t o = (int64_t)t * H * 32 + j * 32 + c;
-                    v = dy_in[o];
-                    if (DIRS == 2) v += dy_in[dy_dir + o];
-                }
-                n_dy[i] = v;
-            }
-            // [h_{prev} | x_t] rows of this lane's columns, curves 16 hf .. 16 hf + 15
-            {
-                const float* hp = tape_ld + (int64_t)tp * ts + 5 * H * 32 + cl * 32 + 16 * hf;
+                n_q[5][i] = tqp[(4 * H + j) * 32];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    n_xh[0][q] = step > 0 ? *reinterpret_cast<const f32x4*>(hp + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int pd = 0; pd < DIRS; ++pd)
+                    n_dy[pd][i] = dy0[(has_dy ? (int64_t)pd * dy_dir + (int64_t)t * H * 32 : 0) + j * 32 + c];
             }
+            // [h_{prev} | x_t] rows of this lane's columns (this role's tiles), curves 16 hf .. 16 hf + 15
 #pragma unroll
-            for (int nt = 1; nt < NT; ++nt) {
-                const int k = 32 * (nt - 1) + cl;
-                const float* src = nullptr;
-                if (FIRST) {
-                    if (k < y.Dp) src = xtile + ((int64_t)t * y.Dp + k) * 32 + 16 * hf;
-                } else if (k < DIRS * H) {
-                    const int dd = k / H, kk = k - dd * H;
-                    src = tape + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + 16 * hf;
+            for (int m = 0; m < MYNT; ++m) {
+                const int nt = T0 + m;
+                const float* src;
+                int k = 0;
+                if (nt == 0) {
+                    src = tape_ld + (int64_t)tpc * ts + 5 * H * 32 + cl * 32 + 16 * hf;
+                } else {
+                    k = 32 * (nt - 1) + cl;
+                    if (FIRST) {
+                        const int kc = k < y.Dp ? k : y.Dp - 1;              // clamped: columns >= Dp are zeroed when consumed
+                        src = xtile + ((int64_t)t * y.Dp + kc) * 32 + 16 * hf;
+                    } else {
+                        const int kc = k < DIRS * H ? k : DIRS * H - 1;
+                        const int dd = kc / H, kk = kc - dd * H;
+                        src = tape + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + 16 * hf;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = src ? *reinterpret_cast<const f32x4*>(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (masked && src) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+                    if (masked && nt > 0) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int o = origs[16 * hf + 4 * q + e];
-                            if (o >= 0)
-                                v[e] = __fmul_rn(FIRST ? (k < y.D ? mask_in(p.mk, 0, p.n_curves, y.D, o, k) : 1.0f)
+                            if (o >= 0 && k < (FIRST ? y.D : DIRS * H))
+                                v[e] = __fmul_rn(FIRST ? mask_in(p.mk, 0, p.n_curves, y.D, o, k)
                                                        : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
                         }
                     }
-                    n_xh[nt][q] = v;
+                    n_xh[m][q] = v;
                 }
             }
         };
@@ -615,29 +629,36 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
             const int tp = d == 0 ? t - 1 : t + 1;
             const bool valid = t < len;
             const bool prev_live = step > 0 && tp < len;
-            float q_[5][UPT], dyv[UPT];
-            f32x4 xh[NT][4];
+            float q_[6][UPT], dyv[UPT];
+            f32x4 xh[MYNT > 0 ? MYNT : 1][4];
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) q_[q][i] = n_q[q][i];
-                dyv[i] = n_dy[i];
+                for (int q = 0; q < 6; ++q) q_[q][i] = n_q[q][i];
+                dyv[i] = n_dy[0][i];
+                if (DIRS == 2) dyv[i] += n_dy[DIRS - 1][i];
+                if (!has_dy) dyv[i] = 0.0f;
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int m = 0; m < MYNT; ++m) {
+                // h_prev of the first processed step is 0; columns beyond the input width do not exist
+                const bool live = T0 + m == 0 ? step > 0 : 32 * (T0 + m - 1) + cl < (FIRST ? y.Dp : DIRS * H);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xh[nt][q] = n_xh[nt][q];
-            if (step > 0) fetch(step - 1);     // n_q[4] is then c of the step this one started from
-            // ---- gate gradients of this thread's 4 units (curve c)
+                for (int q = 0; q < 4; ++q) xh[m][q] = live ? n_xh[m][q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#ifndef SNN_ABL_STREAM_NOLOADS      // timing ablation only (results are wrong): the step without its global loads
+            if (step > 0) fetch(step - 1);
+#endif
+            // ---- gate gradients of this thread's 2 units (curve c)
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-                const int j = jg + 8 * i;
+                const int j = jg + 16 * i;
                 float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
                 if (valid) {
                     const float ig = q_[0][i], fg = q_[1][i], gg = q_[2][i], og = q_[3][i], cn = q_[4][i];
                     float dh = dhr[i] + dyv[i];
                     if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
-                    const float cp = prev_live ? n_q[4][i] : 0.0f;
+                    const float cp = prev_live ? q_[5][i] : 0.0f;
                     const float tc = snn_tanh(cn);
                     const float dct = dc[i] + dh * og * (1.0f - tc * tc);
                     dao = dh * tc * og * (1.0f - og);
@@ -653,21 +674,20 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
                 db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
             }
             __syncthreads();
-            // ---- dh_{prev} and dy of the layer below: K = this wave's 32 gate rows
-            {
-                f32x16 ah, ax[MTX];
+#ifndef SNN_ABL_STREAM_NOMFMA       // timing ablation only (results are wrong): the step without its matrix products
+            // ---- dh_{prev} (role 0) / dy of the layer below (role 1): K = this SIMD's 32 gate rows
+            if (DO_REC || DO_DX) {
+                f32x16 ax[DO_DX ? MTX : 1];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    ah[i] = 0.0f;
+                for (int mt = 0; mt < (DO_DX ? MTX : 1); ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < MTX; ++mt) ax[mt][i] = 0.0f;
-                }
+                    for (int i = 0; i < 16; ++i) ax[mt][i] = 0.0f;
                 const float* b = dGl + (32 * w + hf) * SP + cl;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const float bv = b[2 * kk * SP];
-                    ah = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[kk], bv, ah, 0, 0, 0);
-                    if (!FIRST) {
+                    if (DO_REC) ax[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[kk], bv, ax[0], 0, 0, 0);
+                    if (DO_DX) {
 #pragma unroll
                         for (int mt = 0; mt < MTX; ++mt) ax[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aih[mt][kk], bv, ax[mt], 0, 0, 0);
                     }
@@ -675,37 +695,41 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int r = (i & 3) + 8 * (i >> 2) + 4 * hf;
-                    red[(w * H + r) * 32 + cl] = ah[i];
-                    if (!FIRST) {
+                    if (DO_REC) red[(w * H + r) * 32 + cl] = ax[0][i];
+                    if (DO_DX) {
 #pragma unroll
                         for (int mt = 0; mt < MTX; ++mt) red2[((w * MTX + mt) * 32 + r) * 32 + cl] = ax[mt][i];
                     }
                 }
             }
-            // ---- dW += dG_t [h_prev | x_t]^T : A = this wave's 32 gate rows, k-step kk = curves {kk, kk + 16}
-            {
+            // ---- dW += dG_t [h_prev | x_t]^T : A = this SIMD's 32 gate rows, k-step kk = curves {kk, kk + 16}
+            if (MYNT > 0) {
                 const float* a = dGl + (32 * w + cl) * SP + 16 * hf;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     const float av = a[kk];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[nt][kk >> 2][kk & 3], acc[nt], 0, 0, 0);
+                    for (int m = 0; m < MYNT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[m][kk >> 2][kk & 3], acc[m], 0, 0, 0);
                 }
             }
+#else
+#pragma unroll
+            for (int m = 0; m < MYNT; ++m) acc[m][0] += dGl[tid] * xh[m][0][0] + xh[m][1][1] + xh[m][2][2] + xh[m][3][3];
+#endif
             __syncthreads();
             if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
 #pragma unroll
                 for (int i = 0; i < UPT; ++i) {
-                    const int j = jg + 8 * i;
+                    const int j = jg + 16 * i;
                     dhr[i] = ((red[(0 * H + j) * 32 + c] + red[(1 * H + j) * 32 + c]) + red[(2 * H + j) * 32 + c]) + red[(3 * H + j) * 32 + c];
                 }
             }
             if (!FIRST) {
                 const int o = origs[c];
 #pragma unroll
-                for (int i = 0; i < MTX * 4; ++i) {
-                    const int f = jg + 8 * i, mt = f >> 5, r = f & 31;
+                for (int i = 0; i < MTX * 2; ++i) {
+                    const int f = jg + 16 * i, mt = f >> 5, r = f & 31;
                     float s = ((red2[((0 * MTX + mt) * 32 + r) * 32 + c] + red2[((1 * MTX + mt) * 32 + r) * 32 + c]) +
                                red2[((2 * MTX + mt) * 32 + r) * 32 + c]) + red2[((3 * MTX + mt) * 32 + r) * 32 + c];
                     if (masked && o >= 0) s = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, f), s);
@@ -720,14 +744,15 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
     float* slab = p.slabs + (int64_t)blockIdx.x * y.P;
     const int I = y.I[l];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int m = 0; m < MYNT; ++m) {
+        const int nt = T0 + m;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int R = 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            const float v = acc[nt][i];
+            const float v = acc[m][i];
             if (nt == 0) {
-                const float m = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
-                slab[y.c_whh[ld] + (int64_t)R * H + cl] = m * v;
+                const float mm = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
+                slab[y.c_whh[ld] + (int64_t)R * H + cl] = mm * v;
             } else {
                 const int k = 32 * (nt - 1) + cl;
                 if (k < I) slab[y.c_wih[ld] + (int64_t)R * I + k] = v;
@@ -735,16 +760,26 @@ __global__ void __launch_bounds__(256, 1) bwd_stream_kernel(const Bwd2Params p, 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 4 * UPT; ++i) {
         float v = db[i];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (c == 0) {
-            const int R = (i >> 2) * H + jg + 8 * (i & 3);
+            const int R = (i / UPT) * H + jg + 16 * (i % UPT);
             slab[y.c_bih[ld] + R] = v;
             slab[y.c_bhh[ld] + R] = v;
         }
     }
+}
+
+template <int NTX, bool FIRST, int DIRS, bool MASKED>
+__global__ void __launch_bounds__(512, 1) bwd_stream_kernel(const Bwd2Params p, int l, int G, float* dy_out_base,
+                                                           const float* dy_in_base)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // wave-uniform role: both roles execute the same barriers (two per step, two per tile)
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) bwd_stream_role<NTX, FIRST, DIRS, MASKED, 0>(p, l, G, dy_out_base, dy_in_base, smem);
+    else bwd_stream_role<NTX, FIRST, DIRS, MASKED, 1>(p, l, G, dy_out_base, dy_in_base, smem);
 }
 
 // dflat[i] (+)= sum over the G workgroups of the direction parameter i belongs to, fixed order
@@ -806,7 +841,7 @@ static int stream_geom(const SnnLayout& y, int n_tiles, int max_T, StreamGeom* g
         HIP_CHECK(hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, dev));
         cached_dev = dev;
     }
-    g->G = std::max(1, std::min(n_tiles, cached_cus / y.dirs));      // one workgroup per CU, split over the directions
+    g->G = std::max(1, std::min(n_tiles, SNN_STREAM_OCC * cached_cus / y.dirs));   // workgroups per direction
     g->wt_floats = b.wt_floats;
     g->dfeat_floats = b.dfeat_floats;
     g->dy_floats = y.L > 1 ? (int64_t)y.dirs * b.dy_floats : 0;      // one block per producing direction
@@ -822,11 +857,12 @@ int64_t snn_bwd_stream_workspace_bytes(const SnnLayout& y, int n_tiles, int max_
     return rc ? rc : g.total_bytes;
 }
 
-template <int DIRS>
+template <int DIRS, bool MASKED>
 static bwd_stream_t stream_kernel(int ntx, bool first)
 {
-    if (first) return ntx == 1 ? bwd_stream_kernel<1, true, DIRS> : ntx == 2 ? bwd_stream_kernel<2, true, DIRS> : bwd_stream_kernel<3, true, DIRS>;
-    return bwd_stream_kernel<DIRS, false, DIRS>;
+    if (first) return ntx == 1 ? bwd_stream_kernel<1, true, DIRS, MASKED> : ntx == 2 ? bwd_stream_kernel<2, true, DIRS, MASKED>
+                                                                                    : bwd_stream_kernel<3, true, DIRS, MASKED>;
+    return bwd_stream_kernel<DIRS, false, DIRS, MASKED>;
 }
 
 int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t* len_sorted, const int32_t* order,
@@ -863,13 +899,15 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
     for (int l = y.L - 1; l >= 0; --l) {
         const bool first = l == 0;
         const int ntx = first ? (y.Dp + 31) / 32 : y.dirs;
-        bwd_stream_t fn = y.dirs == 2 ? stream_kernel<2>(ntx, first) : stream_kernel<1>(ntx, first);
+        const bool masked = mk.mode != SNN_MASK_NONE;
+        bwd_stream_t fn = y.dirs == 2 ? (masked ? stream_kernel<2, true>(ntx, first) : stream_kernel<2, false>(ntx, first))
+                                      : (masked ? stream_kernel<1, true>(ntx, first) : stream_kernel<1, false>(ntx, first));
         const int mtx = first ? 0 : y.dirs;
         const size_t lds = sizeof(float) * ((size_t)4 * 32 * 33 + 4 * 32 * 32 + (size_t)4 * mtx * 32 * 32 + 32);
         HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         float* dy_out = (l & 1) ? dyA : dyB;          // written by layer l for layer l - 1
         const float* dy_in = (l & 1) ? dyB : dyA;     // written by layer l + 1
-        hipLaunchKernelGGL(fn, dim3(y.dirs * g.G), dim3(256), lds, st, p, l, g.G, dy_out, dy_in);
+        hipLaunchKernelGGL(fn, dim3(y.dirs * g.G), dim3(512), lds, st, p, l, g.G, dy_out, dy_in);
         HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y, g.G, p.slabs,

@@ -461,5 +461,9 @@ def test_streamed_backward_equals_split_backward(D, dirs, pool, C, masked):
         assert scale > 0
         np.testing.assert_allclose(out["stream"], out["split"], rtol=0, atol=2e-5 * scale)
         # deterministic: a second run of the streamed path is bit-identical
-        again = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk()).cpu().numpy()
+        os.environ["SNN_BWD_PATH"] = "stream"
+        try:
+            again = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk()).cpu().numpy()
+        finally:
+            os.environ.pop("SNN_BWD_PATH")
         assert np.array_equal(again, out["stream"])
