@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "snn_kernels.h"
 #include "snn_host.h"
@@ -104,17 +105,23 @@ __global__ void __launch_bounds__(256) head_dfeat_kernel(const Bwd2Params p)
 // dW_out[q][f] = sum over curves dlogits[curve][q] feat[curve][f];  db_out[q] = sum dlogits.  One workgroup per output
 // element: thread k adds sorted positions k, k + 256, ... in order, then a fixed shuffle / LDS tree -- the order depends
 // on the batch only, never on scheduling.
-__global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p)
+__global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p, int n_chunks)
 {
+    // n_chunks == 1: the sum goes straight to dflat.  n_chunks > 1 (streamed path, large batches): chunk ch adds its
+    // share of the sorted positions into slab ch (the head entries of the gradient slabs are otherwise unused) and
+    // stream_reduce_kernel adds the chunks in index order.
     __shared__ float sh[4];
     const SnnLayout& y = p.lay;
-    const int idx = blockIdx.x;   // grid = C * F + C
+    const int n_out = y.C * y.F + y.C;
+    const int idx = blockIdx.x % n_out, ch = blockIdx.x / n_out;
     const int64_t feat0 = (int64_t)y.L * y.dirs * p.max_T * tape_step_floats(y.H);
     const int npos = p.n_tiles * SNN_TILE;
+    const int per = ((npos + n_chunks - 1) / n_chunks + 255) / 256 * 256;
+    const int pos0 = ch * per, pos1 = min(npos, pos0 + per);
     const bool is_w = idx < y.C * y.F;
     const int q = is_w ? idx / y.F : idx - y.C * y.F, f = is_w ? idx - q * y.F : 0;
     float s = 0.0f;
-    for (int pos = threadIdx.x; pos < npos; pos += 256) {
+    for (int pos = pos0 + threadIdx.x; pos < pos1; pos += 256) {
         const int o = p.order[pos];
         if (o < 0) continue;
         const float dl = p.dlogits[(int64_t)o * y.C + q];
@@ -125,8 +132,10 @@ __global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p)
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float* dst = p.dflat + (is_w ? y.c_head_w + idx : y.c_head_b + q);
-        *dst = (p.accumulate ? *dst : 0.0f) + (((sh[0] + sh[1]) + sh[2]) + sh[3]);
+        const float tot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        const int64_t at = is_w ? y.c_head_w + idx : y.c_head_b + q;
+        if (n_chunks == 1) p.dflat[at] = (p.accumulate ? p.dflat[at] : 0.0f) + tot;
+        else p.slabs[(int64_t)ch * y.P + at] = tot;
     }
 }
 
@@ -567,48 +576,63 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
         }
         // q 5 = c of the step before, fetched WITH the step (taken from the next fetch it would make every step wait for
         // loads it has just issued); dy of both producing directions, added when consumed (an add at fetch time waits too)
-        float n_q[6][UPT], n_dy[DIRS][UPT];
-        f32x4 n_xh[MYNT > 0 ? MYNT : 1][4];
+        // Two register sets, used alternately (the step loop is unrolled by two): no copies between "next" and "current".
+        struct StepVals { float q[6][UPT], dy[DIRS][UPT]; f32x4 xh[MYNT > 0 ? MYNT : 1][4]; };
+        StepVals setA, setB;
         const float* dy0 = dy_in ? dy_in : tape_ld;          // last layer: any valid address, value unused
         const bool has_dy = dy_in != nullptr;
-        auto fetch = [&](int step) {
+        const int64_t dy_tstep = has_dy ? (int64_t)H * 32 : 0, dy_pstep = has_dy ? dy_dir : 0;   // no branch inside fetch
+        // Addressing: every load is  uniform base (SGPR pair, advanced per step by scalar adds) + a 32-bit per-thread
+        // offset that does not change over the tile  -- no 64-bit vector address arithmetic inside the step loop.
+        unsigned off_q[5][UPT], off_dy[UPT], off_x[MYNT > 0 ? MYNT : 1];
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int j = jg + 16 * i;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) off_q[q][i] = (unsigned)((q * H + j) * 32 + c);
+            off_dy[i] = (unsigned)(j * 32 + c);
+        }
+#pragma unroll
+        for (int m = 0; m < MYNT; ++m) {
+            const int nt = T0 + m;
+            if (nt == 0) off_x[m] = (unsigned)(cl * 32 + 16 * hf);
+            else {
+                const int k = 32 * (nt - 1) + cl;
+                if (FIRST) off_x[m] = (unsigned)((k < y.Dp ? k : y.Dp - 1) * 32 + 16 * hf);   // clamped: columns >= Dp give dW columns nobody reads
+                else {
+                    const int kc = k < DIRS * H ? k : DIRS * H - 1;
+                    const int dd = kc / H, kk = kc - dd * H;
+                    off_x[m] = (unsigned)((int64_t)dd * p.max_T * ts + kk * 32 + 16 * hf);
+                }
+            }
+        }
+        const float* x_base = FIRST ? xtile : tape + (int64_t)((l - 1) * DIRS) * p.max_T * ts + 5 * H * 32;
+        const int64_t x_step = FIRST ? (int64_t)y.Dp * 32 : ts;
+        auto fetch = [&](int step, StepVals& nv) {
             const int t = d == 0 ? step : T - 1 - step;
             const int tpc = step > 0 ? (d == 0 ? t - 1 : t + 1) : t;      // clamped: step 0 has no predecessor
-            const float* tq = tape_ld + (int64_t)t * ts + c;
-            const float* tqp = tape_ld + (int64_t)tpc * ts + c;
+            const float* tq = tape_ld + (int64_t)t * ts;
+            const float* tqp = tape_ld + (int64_t)tpc * ts;
+            const float* dyb = dy0 + (int64_t)t * dy_tstep;
+            const float* xb = x_base + (int64_t)t * x_step;
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-                const int j = jg + 16 * i;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) n_q[q][i] = tq[(q * H + j) * 32];
-                n_q[5][i] = tqp[(4 * H + j) * 32];
+                for (int q = 0; q < 5; ++q) nv.q[q][i] = tq[off_q[q][i]];
+                nv.q[5][i] = tqp[off_q[4][i]];
 #pragma unroll
-                for (int pd = 0; pd < DIRS; ++pd)
-                    n_dy[pd][i] = dy0[(has_dy ? (int64_t)pd * dy_dir + (int64_t)t * H * 32 : 0) + j * 32 + c];
+                for (int pd = 0; pd < DIRS; ++pd) nv.dy[pd][i] = (dyb + pd * dy_pstep)[off_dy[i]];
             }
             // [h_{prev} | x_t] rows of this lane's columns (this role's tiles), curves 16 hf .. 16 hf + 15
 #pragma unroll
             for (int m = 0; m < MYNT; ++m) {
                 const int nt = T0 + m;
-                const float* src;
-                int k = 0;
-                if (nt == 0) {
-                    src = tape_ld + (int64_t)tpc * ts + 5 * H * 32 + cl * 32 + 16 * hf;
-                } else {
-                    k = 32 * (nt - 1) + cl;
-                    if (FIRST) {
-                        const int kc = k < y.Dp ? k : y.Dp - 1;              // clamped: columns >= Dp are zeroed when consumed
-                        src = xtile + ((int64_t)t * y.Dp + kc) * 32 + 16 * hf;
-                    } else {
-                        const int kc = k < DIRS * H ? k : DIRS * H - 1;
-                        const int dd = kc / H, kk = kc - dd * H;
-                        src = tape + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + 16 * hf;
-                    }
-                }
+                const float* src = (nt == 0 ? tqp + 5 * H * 32 : xb) + off_x[m];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);   // (h_prev of step 0: clamped address, never multiplied)
                     if (masked && nt > 0) {
+                        const int k = 32 * (nt - 1) + cl;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int o = origs[16 * hf + 4 * q + e];
@@ -617,37 +641,43 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                                                        : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
                         }
                     }
-                    n_xh[m][q] = v;
+                    nv.xh[m][q] = v;
                 }
             }
         };
-        if (T > 0) fetch(T - 1);
-
-        for (int sb = 0; sb < T; ++sb) {
-            const int step = T - 1 - sb;
+        // Columns of [h | x] beyond the input width hold a clamped (valid, finite) column's data: the dW columns they
+        // produce are dropped at the write-out, so they need no select.
+        // dy of the layer below is stored one step late: gfx9's vmcnt counts loads and stores together, so the wait for
+        // the tape values at the top of a step also waits for every store issued before it -- a store issued at the end
+        // of the previous step would put its full round trip on the chain.  Issued after that wait instead, it has a
+        // whole step to complete.
+        float pend[MTX * 2];
+        int pend_t = -1;
+        auto flush_pend = [&]() {
+            if (!FIRST && pend_t >= 0) {
+#pragma unroll
+                for (int i = 0; i < MTX * 2; ++i) {
+                    const int f = jg + 16 * i, dd = f / H, j = f - dd * H;
+                    dy_out_base[(int64_t)d * dy_dir + (((int64_t)tile * DIRS + dd) * p.max_T + pend_t) * H * 32 + j * 32 + c] = pend[i];
+                }
+            }
+        };
+        auto do_step = [&](const int step, const StepVals& cv, StepVals& nv) {
             const int t = d == 0 ? step : T - 1 - step;
             const int tp = d == 0 ? t - 1 : t + 1;
             const bool valid = t < len;
             const bool prev_live = step > 0 && tp < len;
-            float q_[6][UPT], dyv[UPT];
-            f32x4 xh[MYNT > 0 ? MYNT : 1][4];
+            const auto& q_ = cv.q;
+            const auto& xh = cv.xh;
+            float dyv[UPT];
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) q_[q][i] = n_q[q][i];
-                dyv[i] = n_dy[0][i];
-                if (DIRS == 2) dyv[i] += n_dy[DIRS - 1][i];
+                dyv[i] = cv.dy[0][i];
+                if (DIRS == 2) dyv[i] += cv.dy[DIRS - 1][i];
                 if (!has_dy) dyv[i] = 0.0f;
             }
-#pragma unroll
-            for (int m = 0; m < MYNT; ++m) {
-                // h_prev of the first processed step is 0; columns beyond the input width do not exist
-                const bool live = T0 + m == 0 ? step > 0 : 32 * (T0 + m - 1) + cl < (FIRST ? y.Dp : DIRS * H);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xh[m][q] = live ? n_xh[m][q] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
 #ifndef SNN_ABL_STREAM_NOLOADS      // timing ablation only (results are wrong): the step without its global loads
-            if (step > 0) fetch(step - 1);
+            if (step > 0) fetch(step - 1, nv);
 #endif
             // ---- gate gradients of this thread's 2 units (curve c)
 #pragma unroll
@@ -673,6 +703,7 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 dGl[(3 * H + j) * SP + c] = dao;
                 db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
             }
+            flush_pend();          // the previous step's dy (the tape values of this step have landed: see above)
             __syncthreads();
 #ifndef SNN_ABL_STREAM_NOMFMA       // timing ablation only (results are wrong): the step without its matrix products
             // ---- dh_{prev} (role 0) / dy of the layer below (role 1): K = this SIMD's 32 gate rows
@@ -705,13 +736,19 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
             // ---- dW += dG_t [h_prev | x_t]^T : A = this SIMD's 32 gate rows, k-step kk = curves {kk, kk + 16}
             if (MYNT > 0) {
                 const float* a = dGl + (32 * w + cl) * SP + 16 * hf;
+                // h_prev of the first processed step is 0: that step (once per tile, uniform) skips the products of tile 0
+                auto dw = [&](auto skip0) {
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const float av = a[kk];
+                    for (int kk = 0; kk < 16; ++kk) {
+                        const float av = a[kk];
 #pragma unroll
-                    for (int m = 0; m < MYNT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[m][kk >> 2][kk & 3], acc[m], 0, 0, 0);
-                }
+                        for (int m = 0; m < MYNT; ++m)
+                            if (!(decltype(skip0)::value && T0 + m == 0))
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[m][kk >> 2][kk & 3], acc[m], 0, 0, 0);
+                    }
+                };
+                if (ROLE == 0 && step == 0) dw(std::true_type{});
+                else dw(std::false_type{});
             }
 #else
 #pragma unroll
@@ -733,11 +770,19 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                     float s = ((red2[((0 * MTX + mt) * 32 + r) * 32 + c] + red2[((1 * MTX + mt) * 32 + r) * 32 + c]) +
                                red2[((2 * MTX + mt) * 32 + r) * 32 + c]) + red2[((3 * MTX + mt) * 32 + r) * 32 + c];
                     if (masked && o >= 0) s = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, f), s);
-                    const int dd = f / H, j = f - dd * H;
-                    dy_out_base[(int64_t)d * dy_dir + (((int64_t)tile * DIRS + dd) * p.max_T + t) * H * 32 + j * 32 + c] = s;
+                    pend[i] = s;
                 }
+                pend_t = t;
             }
+        };
+        if (T > 0) fetch(T - 1, setA);
+        int step = T - 1;
+        for (; step >= 1; step -= 2) {
+            do_step(step, setA, setB);
+            do_step(step - 1, setB, setA);
         }
+        if (step == 0) do_step(0, setA, setB);
+        flush_pend();
     }
 
     // ---- this workgroup's partial sums -> its slab (canonical layout, only the (layer, direction) slices it owns)
@@ -783,11 +828,19 @@ __global__ void __launch_bounds__(512, 1) bwd_stream_kernel(const Bwd2Params p, 
 }
 
 // dflat[i] (+)= sum over the G workgroups of the direction parameter i belongs to, fixed order
-__global__ void __launch_bounds__(256) stream_reduce_kernel(SnnLayout y, int G, const float* __restrict__ slabs,
-                                                           float* __restrict__ out, int accumulate)
+__global__ void __launch_bounds__(256) stream_reduce_kernel(SnnLayout y, int G, int head_chunks,
+                                                           const float* __restrict__ slabs, float* __restrict__ out,
+                                                           int accumulate)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= y.c_head_w) return;
+    if (i >= y.P) return;
+    if (i >= y.c_head_w) {          // output layer: head_dw_kernel's chunks (one chunk wrote dflat itself)
+        if (head_chunks == 1) return;
+        float s = accumulate ? out[i] : 0.0f;
+        for (int k = 0; k < head_chunks; ++k) s += slabs[(int64_t)k * y.P + i];
+        out[i] = s;
+        return;
+    }
     int ld = 0;
     const int nld = y.L * y.dirs;
     while (ld + 1 < nld && i >= y.c_wih[ld + 1]) ++ld;
@@ -894,7 +947,9 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
     const int n_ld = y.L * y.dirs;
     hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
     hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p);
+    // output-layer gradient: one chunk of sorted positions per 2048 curves, at most one per gradient slab
+    const int head_chunks = std::max(1, std::min(y.dirs * g.G, p.n_tiles * SNN_TILE / 2048));
+    hipLaunchKernelGGL(head_dw_kernel, dim3((y.C * y.F + y.C) * head_chunks), dim3(256), 0, st, p, head_chunks);
     HIP_CHECK(hipGetLastError());
     for (int l = y.L - 1; l >= 0; --l) {
         const bool first = l == 0;
@@ -910,7 +965,7 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
         hipLaunchKernelGGL(fn, dim3(y.dirs * g.G), dim3(512), lds, st, p, l, g.G, dy_out, dy_in);
         HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y, g.G, p.slabs,
+    hipLaunchKernelGGL(stream_reduce_kernel, dim3((unsigned)((y.P + 255) / 256)), dim3(256), 0, st, y, g.G, head_chunks, p.slabs,
                        p.dflat, p.accumulate);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
@@ -933,7 +988,7 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     const int n_ld = y.L * y.dirs;
     hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
     hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p, 1);
     HIP_CHECK(hipGetLastError());
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);
