@@ -202,6 +202,17 @@ int snn_featurize_fill(int64_t n, int64_t n_rows, int32_t F, const int64_t *orde
                        double *flux_out, double *err_out, uint8_t *present_out, double *row_mjd);
 
 /*
+ * Host-only: gather the elements of a variable-length HDF5 dataset -- the light curves `hf["data"]` of database.h5
+ * (written at utils/data_utils.py:691-733, read back one Python object per curve by h5py at utils/training_utils.py:271)
+ * -- from the global heap of the memory-mapped file into ONE caller buffer.  file / file_size: the mapped file;
+ * desc: n 16-byte element records of the dataset {uint32 length, uint64 heap collection address, uint32 object index};
+ * elem_size: bytes per element (4 for float32); out receives sum(length) * elem_size bytes, element after element.
+ * Used by supernnova_amd/utils/h5reader.py (the reader for images without h5py).
+ */
+int snn_h5_vlen_gather(const void *file, int64_t file_size, const void *desc, int64_t n, int32_t elem_size,
+                       void *out, int64_t out_bytes);
+
+/*
  * Re-lay ONE canonical flat weight set (P floats) into kernel layout (PK
  * floats).  Used for torch.nn.LSTM / nn.Linear weights of VanillaRNN and
  * VariationalRNN (vanilla_rnn.py:26-34, variational_rnn.py:37-52).

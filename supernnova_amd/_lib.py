@@ -60,6 +60,7 @@ SIGNATURES = {
     "snn_x_step_floats": (ctypes.c_int64, [_CFG]),
     "snn_featurize_plan": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, _P, _P, ctypes.c_double, _P, _P, _P, _P]),
     "snn_featurize_fill": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32] + [_P] * 10),
+    "snn_h5_vlen_gather": (ctypes.c_int, [_P, ctypes.c_int64, _P, ctypes.c_int64, ctypes.c_int32, _P, ctypes.c_int64]),
     "snn_plan_build": (ctypes.c_int, [_CFG, _I32P, ctypes.c_int32, _I32P, _I32P, _I32P, _I64P]),
     "snn_pack_x": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P,
                                   ctypes.c_int32, ctypes.c_int64, _P, _P]),

@@ -110,6 +110,9 @@ class FakeDataset:
 
 
 class FakeH5(dict):
+    def keys(self):                      # h5py lists a group's members in name order
+        return sorted(dict.keys(self))
+
     def __enter__(self):
         return self
 
