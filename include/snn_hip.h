@@ -64,10 +64,11 @@ typedef struct snn_cfg {
  * SNN_CELL_LSTM  torch.nn.LSTM stack (gate blocks i, f, g, o): every entry point.
  * SNN_CELL_GRU   torch.nn.GRU stack (gate blocks r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
  *                h' = (1 - z) * n + z * h), and
- * SNN_CELL_RNN   torch.nn.RNN stack with tanh: VanillaRNN's other two layer types.  Inference only, SNN_PREC_F32,
- *                no masks, hidden sizes 32 and 64: snn_param_count / snn_kparam_count / snn_prepare_weights(_multi) /
- *                snn_lstm_forward take them (canonical tensors have 3H resp. H rows); the training and Bayesian entry
- *                points return SNN_ERR_UNSUPPORTED.
+ * SNN_CELL_RNN   torch.nn.RNN stack with tanh: VanillaRNN's other two layer types (vanilla_rnn.py:26-32), SNN_PREC_F32,
+ *                hidden sizes 32 and 64.  snn_param_count / snn_kparam_count / snn_prepare_weights(_multi) /
+ *                snn_lstm_forward (no masks), snn_lstm_forward_train (masks allowed), snn_train_tape_floats and
+ *                snn_lstm_backward take them (canonical tensors have 3H resp. H rows; the tape keeps r, z, n and
+ *                W_hn h + b_hn resp. h in the LSTM's slots); the Bayesian entry points return SNN_ERR_UNSUPPORTED.
  */
 #define SNN_CELL_LSTM 0
 #define SNN_CELL_GRU 1

@@ -315,7 +315,7 @@ extern "C" int32_t snn_feat(const snn_cfg* cfg)
 // ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; fwd_layer_kernel_t fn_train_layer; };
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; };
 struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; fwd_layer_kernel_t fn_train_layer; };
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
@@ -331,8 +331,9 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
     if (y.prec != 0) return nullptr;   // the bf16 x 3 kernels have their own launcher
     const FwdSmallEntry* e = y.H == 32 ? snn_fwd_small_h32(y.KKI[0], y.dirs)
                            : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
-    if (e && y.cell != 0) {   // GRU / tanh RNN: un-masked inference kernel only
-        ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr, nullptr, false, nullptr};
+    if (e && y.cell != 0) {   // GRU / tanh RNN: un-masked inference kernel + the training kernel (which takes masks)
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr,
+                       y.cell == 1 ? e->fn_gru_train : e->fn_rnn_train, false, nullptr};
         return &ent;
     }
     if (y.cell != 0) return nullptr;
@@ -662,6 +663,10 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     if (max_T < 1) { snn_set_error("max_T < 1"); return SNN_ERR_ARG; }
     FwdGeom g, gt;
     rc = fwd_geom(y, e->fn, e->big, max_T, &g);
+    if (!rc && !e->big && y.cell != 0) {
+        rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
+        if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+    }
     if (!rc && !e->big && y.cell == 0) {
         rc = fwd_geom(y, e->fn_masked, false, max_T, &gt);
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
@@ -709,7 +714,6 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    if (train && (rc = snn_lstm_only(y, "snn_lstm_forward_train"))) return rc;
     const FwdEntry* e = find_fwd(y);
     if (!e && y.prec == 0) { snn_set_error("no forward kernel for H=%d D=%d dirs=%d cell=%d", y.H, y.D, y.dirs, y.cell); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !workspace || (!out_logits && !out_probs)) {
@@ -855,7 +859,6 @@ extern "C" int64_t snn_train_tape_floats(const snn_cfg* cfg, int32_t n_tiles, in
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    if ((rc = snn_lstm_only(y, "snn_train_tape_floats"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_train_tape_floats: bad sizes"); return SNN_ERR_ARG; }
     return tape_tile_floats(y.H, y.L * y.dirs, max_T, y.F) * n_tiles;
 }

@@ -190,6 +190,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
                 const float zg = snn_sigmoid(acc[4 + u]);
                 const float ng = snn_tanh(fmaf(rg, acc[12 + u], acc[8 + u]));
                 hv = fmaf(zg, hst[u] - ng, ng);   // (1 - z) n + z h
+                if (TRAIN) { ig = rg; fg = zg; gg = ng; og = acc[12 + u]; }   // tape slots 0..3: r, z, n, W_hn h + b_hn
             } else if (CELL == 2) {
                 hv = snn_tanh(acc[u]);
             } else {
@@ -423,7 +424,7 @@ lstm_fwd_train_layer_kernel(const FwdParams p, int l, float* __restrict__ head_p
 // ---- instantiation lists ------------------------------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn; fwd_layer_kernel_t fn_train_layer; };
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; };
 template <int H, int K, int Dd>
 constexpr fwd_layer_kernel_t train_layer_kernel()
 {
@@ -433,7 +434,8 @@ constexpr fwd_layer_kernel_t train_layer_kernel()
 #define SNN_FWD_ENTRY(H, K, Dd)                                                                       \
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
      lstm_fwd_kernel<H, K, Dd, true, true>, lstm_fwd_kernel<H, K, Dd, false, false, 1>,         \
-     lstm_fwd_kernel<H, K, Dd, false, false, 2>, train_layer_kernel<H, K, Dd>()}
+     lstm_fwd_kernel<H, K, Dd, false, false, 2>, lstm_fwd_kernel<H, K, Dd, true, true, 1>,      \
+     lstm_fwd_kernel<H, K, Dd, true, true, 2>, train_layer_kernel<H, K, Dd>()}
 // layer-0 k-step buckets of snn_layout.h (D <= 24, 26, 48, 76, 78), both direction counts
 #define SNN_FWD_ENTRIES(H)                                                                              \
     SNN_FWD_ENTRY(H, 12, 2), SNN_FWD_ENTRY(H, 13, 2), SNN_FWD_ENTRY(H, 24, 2), SNN_FWD_ENTRY(H, 38, 2), \

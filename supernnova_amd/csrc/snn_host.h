@@ -6,11 +6,10 @@
 
 void snn_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int snn_make_layout(const snn_cfg* cfg, SnnLayout* y);
-// the training and Bayesian entry points exist for the LSTM cell only (the reference trains GRU / tanh-RNN stacks through
-// torch.nn.GRU / torch.nn.RNN, vanilla_rnn.py:30-40; here those cells have an inference kernel)
+// the Bayesian entry points exist for the LSTM cell only (bayesian_rnn.py:47-69 registers no other layer type)
 static inline int snn_lstm_only(const SnnLayout& y, const char* fn)
 {
     if (y.cell == 0) return SNN_OK;
-    snn_set_error("%s: cell %d (1 GRU, 2 RNN) is inference-only (snn_prepare_weights* + snn_lstm_forward in SNN_PREC_F32)", fn, y.cell);
+    snn_set_error("%s: cell %d (1 GRU, 2 RNN) has no Bayes-by-Backprop kernels: inference-only here (bayesian_rnn.py:47-69: lstm only)", fn, y.cell);
     return SNN_ERR_UNSUPPORTED;
 }

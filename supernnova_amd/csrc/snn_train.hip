@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) grad_reduce_kernel(int64_t P, int n_slabs
 const BwdEntry* snn_bwd_small_h32(int KKI0, int dirs);   // snn_bwd_h32.hip: fused kernel, H = 32
 static const BwdEntry* find_bwd(const SnnLayout& y)
 {
-    return y.H == 32 ? snn_bwd_small_h32(y.KKI[0], y.dirs) : nullptr;
+    return (y.H == 32 && y.cell == 0) ? snn_bwd_small_h32(y.KKI[0], y.dirs) : nullptr;   // GRU / tanh RNN: split path only
 }
 // H = 32 has both paths.  Measured on MI355X (BayesianRNN train step, lengths U{3..40}), ms per step at batch
 // 128 / 8192 / 16384 / 32768 / 65536: fused 1.32 / 1.66 / 2.57 / 4.05 / 7.43, split 0.59 / 1.33 / 2.25 / 3.73 / 7.08: the
@@ -97,7 +97,6 @@ extern "C" int64_t snn_lstm_backward_workspace_bytes(const snn_cfg* cfg, int32_t
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    if ((rc = snn_lstm_only(y, "snn_lstm_backward_workspace_bytes"))) return rc;
     if (n_tiles < 1 || max_T < 1) { snn_set_error("snn_lstm_backward_workspace_bytes: bad sizes"); return SNN_ERR_ARG; }
     const BwdEntry* fused = find_bwd(y);
     if (use_stream_path(y, n_tiles)) return snn_bwd_stream_workspace_bytes(y, n_tiles, max_T);
@@ -119,7 +118,6 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
     if (rc) return rc;
-    if ((rc = snn_lstm_only(y, "snn_lstm_backward"))) return rc;
     const BwdEntry* e = find_bwd(y);
     if (!e && !snn_bwd_big_supported(y)) { snn_set_error("no backward kernel for H=%d D=%d dirs=%d", y.H, y.D, y.dirs); return SNN_ERR_UNSUPPORTED; }
     if (!xp || !len_sorted || !order || !tile_T || !tile_off || !wk || !tape || !dlogits || !dflat || !workspace) {

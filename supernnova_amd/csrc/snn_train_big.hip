@@ -69,7 +69,6 @@ __global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
     if (which == 1 && l == 0) return;
     const int cols = which == 0 ? H : I;
     const int64_t n = (int64_t)(cols / 32) * 2 * H * 64;
-    const TensorGeom g = tensor_geom(y, 4 * ld + (which == 0 ? 1 : 0));
     float* dst = p.WT + (which == 0 ? p.wt_hh[ld] : p.wt_ih[ld]);
     const bool masked = p.mk.mode != SNN_MASK_NONE;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -77,7 +76,11 @@ __global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
         const int kk = (int)((idx >> 6) % (2 * H));
         const int mt = (int)(idx / ((int64_t)2 * H * 64));
         const int R = 2 * kk + (lane >> 5), col = 32 * mt + (lane & 31);
-        float v = p.wk[kernel_index(y, g, (int64_t)R * cols + col)];
+        // R is a row of the kernel image: row group R / H (LSTM: the gate; GRU: r, z, n input part, n hidden part; RNN:
+        // group 0 only, the rest zero) of hidden unit R % H -- snn_layout.h
+        const int grp = R / H, j = R - grp * H;
+        const int k = which == 0 ? 2 * y.KKI[l] + col : col;
+        float v = p.wk[y.k_A[ld] + ((int64_t)((j >> 3) * y.KK[l] + (k >> 1))) * 64 + (k & 1) * 32 + grp * 8 + (j & 7)];
         if (which == 0 && d == 0 && masked) v = __fmul_rn(mask_whh(p.mk, 0, y.L, H, l, R), v);   // variational_rnn.py:224-238
         dst[idx] = v;
     }
@@ -140,7 +143,10 @@ __global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p, int n_
 }
 
 // ---- the recurrent part ------------------------------------------------------------------------------
-template <int H>
+// CELL 0 LSTM (tape slots i, f, g, o, c, h), 1 GRU (r, z, n, W_hn h + b_hn, -, h), 2 tanh RNN (-, -, -, -, -, h).  The four
+// row groups of dG follow the kernel image: GRU  d(r pre), d(z pre), d(n pre), d(n pre) * r   (input / hidden part of n);
+// RNN  d(pre), 0, 0, 0.
+template <int H, int CELL>
 __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int l)
 {
     constexpr int MT = H / 32;          // output tiles of dh
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
             n_fg[i] = tq[(1 * H + j) * 32];
             n_gg[i] = tq[(2 * H + j) * 32];
             n_og[i] = tq[(3 * H + j) * 32];
-            n_cn[i] = tq[(4 * H + j) * 32];
+            n_cn[i] = tq[((CELL == 0 ? 4 : 5) * H + j) * 32];   // LSTM: c_t; GRU / RNN: h_t
             n_dy[i] = dy ? dy[(int64_t)t * H * 32 + j * 32 + c] : 0.0f;
         }
     };
@@ -216,7 +222,25 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
         for (int i = 0; i < UPT; ++i) {
             const int j = jg + 8 * i;
             float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
-            if (valid) {
+            if (valid && CELL != 0) {
+                float dh = dhr[i];
+                if (dy) dh += dyv[i];
+                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
+                if (CELL == 1) {   // h = (1 - z) n + z h_prev,  n = tanh(a2 + r a3)
+                    const float rg = ig[i], zg = fg[i], ng = gg[i], a3 = og[i];
+                    const float hp = prev_live ? n_cn[i] : 0.0f;
+                    const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
+                    dai = dnp * a3 * rg * (1.0f - rg);
+                    daf = dh * (hp - ng) * zg * (1.0f - zg);
+                    dag = dnp;
+                    dao = dnp * rg;
+                    dc[i] = dh * zg;        // the direct path to h_prev, added to W_hh^T dG below
+                } else {           // h = tanh(a0); cn[] holds h_t
+                    dai = dh * (1.0f - cn[i] * cn[i]);
+                    dc[i] = 0.0f;
+                }
+            }
+            if (valid && CELL == 0) {
                 float dh = dhr[i];
                 if (dy) dh += dyv[i];
                 if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
@@ -260,7 +284,7 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
                 float s = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KSPLIT; ++k) s += red[(k * H + j) * 32 + c];
-                dhr[i] = s;
+                dhr[i] = CELL == 1 ? s + dc[i] : s;
             }
         }
     }
@@ -459,14 +483,19 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
         for (int i = 0; i < 16; ++i) {
             const int R = 128 * mg + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
             const float v = acc[nt][i];
+            // image row -> canonical row of the hidden-side (w_hh, b_hh) / input-side (w_ih, b_ih) tensors; -1: no such row
+            // (GRU: group 2 is the input part of n, group 3 its hidden part; RNN: group 0 only)
+            const int grp = R / H, jr = R - grp * H;
+            const int Rh = y.cell == 0 ? R : y.cell == 1 ? (grp == 2 ? -1 : (grp == 3 ? 2 : grp) * H + jr) : (grp == 0 ? jr : -1);
+            const int Ri = y.cell == 0 ? R : y.cell == 1 ? (grp == 3 ? -1 : R) : (grp == 0 ? jr : -1);
             if (col < H) {
                 const float m = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
-                slab[y.c_whh[ld] + (int64_t)R * H + col] = m * v;
+                if (Rh >= 0) slab[y.c_whh[ld] + (int64_t)Rh * H + col] = m * v;
             } else if (col - H < I) {
-                slab[y.c_wih[ld] + (int64_t)R * I + (col - H)] = v;
+                if (Ri >= 0) slab[y.c_wih[ld] + (int64_t)Ri * I + (col - H)] = v;
             } else if (col == H + I) {
-                slab[y.c_bih[ld] + R] = v;
-                slab[y.c_bhh[ld] + R] = v;
+                if (Ri >= 0) slab[y.c_bih[ld] + Ri] = v;
+                if (Rh >= 0) slab[y.c_bhh[ld] + Rh] = v;
             }
         }
     }
@@ -881,7 +910,7 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
 struct StreamGeom { int G; int64_t wt_floats, dfeat_floats, dy_floats, slab_floats, total_bytes; };
 typedef void (*bwd_stream_t)(const Bwd2Params, int, int, float*, const float*);
 
-bool snn_bwd_stream_supported(const SnnLayout& y) { return y.H == 32 && y.D <= SNN_MAX_D && y.Dp <= 96; }
+bool snn_bwd_stream_supported(const SnnLayout& y) { return y.cell == 0 && y.H == 32 && y.D <= SNN_MAX_D && y.Dp <= 96; }
 
 static int stream_geom(const SnnLayout& y, int n_tiles, int max_T, StreamGeom* g, int64_t* wt_hh, int64_t* wt_ih)
 {
@@ -971,7 +1000,10 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
     return SNN_OK;
 }
 
-bool snn_bwd_big_supported(const SnnLayout& y) { return (y.H == 32 || y.H == 64 || y.H == 128) && y.D <= SNN_MAX_D; }
+bool snn_bwd_big_supported(const SnnLayout& y)
+{
+    return (y.H == 32 || y.H == 64 || (y.H == 128 && y.cell == 0)) && y.D <= SNN_MAX_D;
+}
 
 int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
 {
@@ -980,7 +1012,7 @@ int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
     return g.total_bytes;
 }
 
-template <int H>
+template <int H, int CELL>
 static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
 {
     Bwd2Params p = p0;
@@ -992,14 +1024,14 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     HIP_CHECK(hipGetLastError());
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);
-    HIP_CHECK(hipFuncSetAttribute((const void*)bwd_rec_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec));
+    HIP_CHECK(hipFuncSetAttribute((const void*)bwd_rec_kernel<H, CELL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec));
     constexpr int NTN_MAX = (H + 2 * H + 1 + 31) / 32;   // widest layer: I = 2H (or D <= 78 <= 2H for H >= 64)
     float* dyA = p.dfeat + g.dfeat_floats + g.dG_floats;
     float* dyB = dyA + g.dy_floats;
     for (int l = y.L - 1; l >= 0; --l) {
         p.dy_in = (l & 1) ? dyA : dyB;    // written by the layer above
         p.dy_out = (l & 1) ? dyB : dyA;
-        hipLaunchKernelGGL(bwd_rec_kernel<H>, dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
+        hipLaunchKernelGGL((bwd_rec_kernel<H, CELL>), dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
         HIP_CHECK(hipGetLastError());
         if (l > 0) {
             const int n_tchunks = (p.max_T + 3) / 4;
@@ -1044,9 +1076,14 @@ int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* le
     p.dflat = dflat;
     p.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
-    if (y.H == 128) return launch_big<128>(p, g, st);
-    if (y.H == 64) return launch_big<64>(p, g, st);
-    if (y.H == 32) return launch_big<32>(p, g, st);
+    if (y.cell == 1 && y.H == 64) return launch_big<64, 1>(p, g, st);
+    if (y.cell == 1 && y.H == 32) return launch_big<32, 1>(p, g, st);
+    if (y.cell == 2 && y.H == 64) return launch_big<64, 2>(p, g, st);
+    if (y.cell == 2 && y.H == 32) return launch_big<32, 2>(p, g, st);
+    if (y.cell != 0) { snn_set_error("no backward kernel for cell %d at H=%d", y.cell, y.H); return SNN_ERR_UNSUPPORTED; }
+    if (y.H == 128) return launch_big<128, 0>(p, g, st);
+    if (y.H == 64) return launch_big<64, 0>(p, g, st);
+    if (y.H == 32) return launch_big<32, 0>(p, g, st);
     snn_set_error("no backward kernel for H=%d", y.H);
     return SNN_ERR_UNSUPPORTED;
 }

@@ -40,7 +40,7 @@ class Config:
     nb_classes: int = 2
     pool: str = "mean"
     precision: str = "f32"      # "f32" | "bf16x3" | "f16x2" (include/snn_hip.h: SNN_PREC_*; the last two inference only)
-    cell: str = "lstm"          # settings.layer_type: "lstm" | "gru" | "rnn" (SNN_CELL_*; gru / rnn inference only, f32)
+    cell: str = "lstm"          # settings.layer_type: "lstm" | "gru" | "rnn" (SNN_CELL_*; gru / rnn: f32, H 32 / 64, no Bayesian path)
 
     @property
     def c(self):

@@ -231,11 +231,7 @@ class _HipRNN(nn.Module):
         return int(torch.empty((), dtype=torch.int64).random_().item())
 
     def _use_train_path(self):
-        train = self.training and torch.is_grad_enabled()
-        if train and self.layer_type != "lstm":
-            raise L.SnnError(f"layer_type {self.layer_type!r} has inference kernels only: call .eval() or run under "
-                             "torch.no_grad() (training kernels exist for 'lstm')")
-        return train
+        return self.training and torch.is_grad_enabled()
 
     def _train_forward(self, x, masks_fn, eps=None, mean_field_inference=False):
         """Differentiable forward (autograd.Function over the HIP train/backward kernels)."""
@@ -248,8 +244,6 @@ class _HipRNN(nn.Module):
     def fused_train_step(self, x, target, optimizer, kl_scale=0.0, eps=None, masks=None):
         """One training step without autograd (utils/training_utils.py:508-525 in five launches):
         forward-train, CE + dlogits, BPTT, (BBB backward), fused Adam.  Returns the loss (device scalar)."""
-        if self.layer_type != "lstm":
-            raise L.SnnError(f"layer_type {self.layer_type!r} has inference kernels only (training kernels exist for 'lstm')")
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
@@ -318,7 +312,7 @@ class _HipRNN(nn.Module):
 class VanillaRNN(_HipRNN):
     def __init__(self, input_size, settings):
         super().__init__()
-        # layer_type gru / rnn (vanilla_rnn.py:26-32: getattr(torch.nn, layer_type.upper())): inference kernels only
+        # layer_type gru / rnn (vanilla_rnn.py:26-32: getattr(torch.nn, layer_type.upper())): fp32 kernels, H = 32 / 64
         self._init_common(input_size, settings, ("lstm", "gru", "rnn"))
         self.dropout = settings.dropout
         self.rnn_layer = _LSTMParams(input_size, self.hidden_size, self.num_layers, self.bidirectional, self.layer_type)
@@ -347,6 +341,10 @@ class VanillaRNN(_HipRNN):
             # train mode under torch.no_grad(): the reference still applies nn.LSTM's and nn.Dropout's dropout
             # (vanilla_rnn.py:26-33) -- grad mode only decides whether a tape is kept, not whether masks are drawn
             masks = self._masks
+            if self.layer_type != "lstm":      # GRU / tanh RNN take masks in their training kernel only: run it, drop the tape
+                with torch.no_grad():
+                    logits, _ = self._train_forward(x, masks)
+                return logits
         wk = E.prepare_weights(self.infer_cfg(masks is not None), self._flat("w"))
         (logits, _), _ = self._launch(x, wk, 1, masks)
         return logits[0]

@@ -441,8 +441,8 @@ def test_gru_rnn_are_inference_only():
     plan = E.Plan(cfg, lengths, DEV)
     xp = E.pack_x(cfg, plan, _t(x))
     wk = E.prepare_weights(cfg, torch.zeros(cfg.P, device=DEV))
-    with pytest.raises(L.SnnError, match="inference-only"):
-        E.lstm_forward_train(cfg, plan, xp, wk)
+    with pytest.raises(L.SnnError, match="inference-only"):          # Bayes-by-Backprop exists for the LSTM cell only
+        E.bbb_sample(cfg, torch.zeros(cfg.P, device=DEV), torch.zeros(cfg.P - 2, device=DEV), 1, E.Prior())
     masks = E.Masks(mode=L.SNN_MASK_PHILOX, which=8, dropout=0.1, seed=1)
     with pytest.raises(L.SnnError, match="masked"):
         E.lstm_forward(cfg, plan, xp, wk, 1, masks=masks)

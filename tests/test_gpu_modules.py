@@ -222,9 +222,12 @@ def test_vanilla_module_gru_rnn(cell, pool, kw, D):
         _close(rnn(torch.from_numpy(g["x"]).to(DEV)), g["logits_dense"])
         probs = rnn.forward_mc(_packed(g), 2).cpu().numpy()
     assert rel_err(probs[:, 0], g["probs"]) < PROB_RTOL and np.array_equal(probs[:, 0], probs[:, 1])
+    # train mode: the GRU / tanh-RNN training kernels (round 2); with dropout 0 the logits are the eval-mode ones
     rnn.train()
-    with pytest.raises(L.SnnError, match="inference kernels only"):
-        rnn(_packed(g))
+    rnn.dropout = 0.0
+    out = rnn(_packed(g))
+    assert out.requires_grad
+    _close(out, g["logits"])
 
 
 def test_vanilla_train_mode_without_grad_still_applies_dropout():

@@ -467,3 +467,47 @@ def test_streamed_backward_equals_split_backward(D, dirs, pool, C, masked):
         finally:
             os.environ.pop("SNN_BWD_PATH")
         assert np.array_equal(again, out["stream"])
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("tag", ["mean", "standard"])
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+def test_gru_rnn_train_step_two_adam_steps(cell, tag, fused):
+    """f4: VanillaRNN with layer_type gru / rnn trains on the HIP kernels (forward with tape, split BPTT with the cell's
+    gate algebra, fused Adam): loss, every gradient and the parameters after each of two Adam steps of the REFERENCE run
+    (fixture g12: reference VanillaRNN over torch.nn.GRU / torch.nn.RNN through its train step), for a bidirectional
+    mean-pooled H=32 model and a unidirectional standard-pooled H=64, 3-class one."""
+    from test_host_logic import settings
+    from supernnova_amd.utils import training_utils as tu
+    g = load_golden(f"g12_train_{cell}_{tag}")
+    st = settings(model="vanilla", layer_type=cell, dropout=0.0, use_cuda=True, hidden_dim=int(g["hidden"]),
+                  nb_classes=int(g["nb_classes"]), bidirectional=bool(g["bidirectional"]), rnn_output_option=str(g["pool"]))
+    rnn = tu.get_model(st, g["x"].shape[2])
+    rnn.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in g["sd0"].items()})
+    rnn.to(DEV)
+    opt = tu.get_optimizer(st, rnn)
+    packed = pack_padded_sequence(_t(g["x"]), torch.from_numpy(g["lengths"].astype(np.int64)))
+    target = _t(g["target"], np.int64)
+    crit = torch.nn.CrossEntropyLoss()
+    B = len(g["target"])
+    for it in range(2):
+        if fused:
+            loss = tu.train_step_fused(st, rnn, packed, target, opt, B, 7)
+        else:
+            rnn.train()
+            opt.zero_grad()
+            out = rnn(packed)
+            np.testing.assert_allclose(out.detach().cpu().numpy(), g["logits"][it], atol=LOGIT_ATOL, rtol=0)
+            loss = crit(out.squeeze(), target)
+            loss.backward()
+            for k, p in rnn.named_parameters():
+                _grad_check(p.grad.cpu().numpy(), g[f"grads{it}"][k], k)
+            opt.step()
+        assert abs(float(loss) - g["loss"][it]) < 3e-6 * max(1.0, abs(g["loss"][it]))
+        ref = g[f"sd{it + 1}"]
+        for k, v in rnn.state_dict().items():
+            gmag = np.minimum(*[np.abs(g[f"grads{j}"][k]) for j in (0, it)]).astype(np.float64)
+            dg = GRAD_RTOL * max(np.abs(g[f"grads{j}"][k]).max() for j in (0, it))
+            bound = 1e-3 * np.minimum(2.0, (1 + 2 * it) * dg * 1e-8 / (gmag + 1e-8) ** 2) + 3e-7
+            err = np.abs(v.cpu().numpy().astype(np.float64) - ref[k])
+            assert (err <= bound).all(), (it, k, float(err.max()), float((err / bound).max()))

@@ -439,6 +439,38 @@ def g4_train():
         save(f"g4_train_{model}", **arrs)
 
 
+# ---------------------------------------------------------------- G12 GRU / tanh-RNN train steps
+def g12_train_cells():
+    """VanillaRNN with layer_type gru / rnn (vanilla_rnn.py:26-32 -> torch.nn.GRU / torch.nn.RNN) through the reference's
+    train step (utils/training_utils.py:508-525): loss, every gradient, parameters after each of two Adam steps.
+    dropout = 0 (no draws to replay); one bidirectional mean-pooled and one unidirectional standard-pooled model each."""
+    T, B = 21, 40
+    for cell in ("gru", "rnn"):
+        for tag, kw, D in (("mean", {}, 24), ("standard", dict(rnn_output_option="standard", bidirectional=False, nb_classes=3,
+                                                              hidden_dim=64), 26)):
+            st = settings(layer_type=cell, dropout=0.0, **kw)
+            torch.manual_seed(121)
+            m = build(vanilla_rnn.VanillaRNN, D, st)
+            sd0 = sd_np(m)
+            x, lengths = make_batch(122, T, B, D)
+            target = np.random.default_rng(123).integers(0, st.nb_classes, size=B).astype(np.int64)
+            packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lengths))
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0)
+            arrs = dict(sd0=sd0, x=x, lengths=lengths, target=target, hidden=np.int64(st.hidden_dim),
+                        nb_classes=np.int64(st.nb_classes), bidirectional=np.int64(st.bidirectional),
+                        pool=np.array(st.rnn_output_option))
+            losses, outs = [], []
+            for it in range(2):
+                loss, grads, out = ref_train_step(m, packed, torch.from_numpy(target), opt, B, 7, False)
+                losses.append(loss)
+                outs.append(out)
+                arrs[f"grads{it}"] = grads
+                arrs[f"sd{it + 1}"] = sd_np(m)
+            arrs["loss"] = np.array(losses, np.float64)
+            arrs["logits"] = np.stack(outs)
+            save(f"g12_train_{cell}_{tag}", **arrs)
+
+
 # ---------------------------------------------------------------- G5 MC statistics
 def g5_mc_stats():
     D, T, B, S = 24, 40, 256, 50
@@ -931,6 +963,8 @@ if __name__ == "__main__":
         g10_predictions()
     if "g11" in which:
         g11_loader()
+    if "g12" in which:
+        g12_train_cells()
     if "g8" in which:
         g8_swag()
     if "g9" in which:
