@@ -364,6 +364,12 @@ int snn_adam_step(int64_t n, float *params, const float *grads, float *exp_avg, 
                   int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                   float grad_scale, void *stream);
 
+/* torch.optim.SGD (momentum, L2 weight decay, dampening 0, no Nesterov) over a flat buffer: the optimizer of the
+ * reference's train_swag_finetune (training/train_rnn.py:541-546).  `step` counts from 1 (step 1 initialises
+ * momentum_buf with the gradient, as torch does); momentum_buf may be NULL when momentum is 0. */
+int snn_sgd_step(int64_t n, float *params, const float *grads, float *momentum_buf, int64_t step, float lr,
+                 float momentum, float weight_decay, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,7 @@ SIGNATURES = {
     "snn_ce_loss_partials": (ctypes.c_int64, [ctypes.c_int32]),
     "snn_ce_loss_grad": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, _P, ctypes.c_float, _P, _P, _P, _P]),
     "snn_adam_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 6 + [_P]),
+    "snn_sgd_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
 }
 
 _lib = None

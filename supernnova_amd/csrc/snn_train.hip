@@ -360,3 +360,36 @@ extern "C" int snn_adam_step(int64_t n, float* params, const float* grads, float
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }
+
+// ============================================================================
+// Fused SGD with momentum over one flat buffer (torch.optim.SGD semantics, dampening 0, no Nesterov:
+// training/train_rnn.py:541-546 -- the optimizer of train_swag_finetune)
+// ============================================================================
+__global__ void __launch_bounds__(256) sgd_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                 float* __restrict__ buf, float lr, float momentum, float weight_decay,
+                                                 int first, float grad_scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float pi = p[i];
+    float gi = g[i] * grad_scale;
+    if (weight_decay != 0.0f) gi = fmaf(weight_decay, pi, gi);
+    if (momentum != 0.0f) {
+        gi = first ? gi : fmaf(momentum, buf[i], gi);      // the first step copies the gradient into the buffer
+        buf[i] = gi;
+    }
+    p[i] = pi - lr * gi;
+}
+
+extern "C" int snn_sgd_step(int64_t n, float* params, const float* grads, float* momentum_buf, int64_t step, float lr,
+                            float momentum, float weight_decay, float grad_scale, void* stream)
+{
+    if (!params || !grads || (momentum != 0.0f && !momentum_buf) || n < 1 || step < 1) {
+        snn_set_error("snn_sgd_step: null pointer, n < 1 or step < 1");
+        return SNN_ERR_ARG;
+    }
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, params, grads,
+                       momentum_buf, lr, momentum, weight_decay, step == 1 ? 1 : 0, grad_scale);
+    HIP_CHECK(hipGetLastError());
+    return SNN_OK;
+}

@@ -470,3 +470,12 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), 
             raise L.SnnError("adam_step: size mismatch")
     L.check(L.load().snn_adam_step(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), step,
                                    lr, betas[0], betas[1], eps, weight_decay, grad_scale, _stream()), "snn_adam_step")
+
+
+def sgd_step(params, grads, momentum_buf, step, lr, momentum=0.0, weight_decay=0.0, grad_scale=1.0):
+    for t, n in ((params, "params"), (grads, "grads"), (momentum_buf, "momentum_buf")):
+        _require_cuda(t, n)
+        if t.numel() != params.numel():
+            raise L.SnnError("sgd_step: size mismatch")
+    L.check(L.load().snn_sgd_step(params.numel(), _ptr(params), _ptr(grads), _ptr(momentum_buf), step, lr, momentum,
+                                  weight_decay, grad_scale, _stream()), "snn_sgd_step")

@@ -1,17 +1,19 @@
-"""Fused Adam over the module's flat parameter buffer (one kernel launch per step), with the
-data-parallel gradient all-reduce folded in.  torch.optim.Adam semantics
-(utils/training_utils.py:365-369): lr, betas (0.9, 0.999), eps 1e-8, L2 weight_decay."""
+"""Fused optimizers over the module's flat parameter buffer (one kernel launch per step), with the
+data-parallel gradient all-reduce folded in.
+  FusedAdam  torch.optim.Adam semantics (utils/training_utils.py:365-369): lr, betas (0.9, 0.999), eps 1e-8, L2 weight_decay
+  FusedSGD   torch.optim.SGD semantics with momentum (training/train_rnn.py:541-546, train_swag_finetune)"""
 import torch
 
 from . import engine as E
 
 
-class FusedAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None):
+class _FlatOptimizer:
+    _buffers = ()
+
+    def __init__(self, model, process_group=None, **hyper):
         self.model = model
-        self.param_groups = [dict(params=list(model.parameters()), lr=lr, betas=betas, eps=eps,
-                                  weight_decay=weight_decay)]
-        self.state = dict(step=0, exp_avg=None, exp_avg_sq=None)
+        self.param_groups = [dict(params=list(model.parameters()), **hyper)]
+        self.state = dict(step=0, **{k: None for k in self._buffers})
         self.process_group = process_group
 
     # -- torch.optim.Optimizer surface used by the reference's loops
@@ -28,7 +30,7 @@ class FusedAdam:
         ps = self.model._flat_params()
         g0 = ps[0].grad
         if g0 is None:
-            raise RuntimeError("FusedAdam.step(): parameters have no gradient (call loss.backward() first)")
+            raise RuntimeError(f"{type(self).__name__}.step(): parameters have no gradient (call loss.backward() first)")
         ptr, contiguous = g0.data_ptr(), True
         for p in ps:
             g = p.grad
@@ -47,21 +49,19 @@ class FusedAdam:
         self.step_flat(self._flat_grads())
 
     def step_flat(self, grads):
-        """Adam update from a gradient already laid out like model.flat_parameters()."""
+        """Update from a gradient already laid out like model.flat_parameters()."""
         from .distributed import allreduce_mean_scale
-        g = self.param_groups[0]
         flat = self.model.flat_parameters()
         if grads.numel() != flat.numel():
-            raise RuntimeError("FusedAdam: flat gradient size does not match the parameters")
+            raise RuntimeError(f"{type(self).__name__}: flat gradient size does not match the parameters")
         # ONE all-reduce of the whole gradient (160-320 KB at H=32): latency-bound over xGMI, so a single call
         scale = allreduce_mean_scale(grads, self.process_group)
         st = self.state
-        if st["exp_avg"] is None or st["exp_avg"].numel() != flat.numel() or st["exp_avg"].device != flat.device:
-            st["exp_avg"] = torch.zeros_like(flat)
-            st["exp_avg_sq"] = torch.zeros_like(flat)
+        for k in self._buffers:
+            if st[k] is None or st[k].numel() != flat.numel() or st[k].device != flat.device:
+                st[k] = torch.zeros_like(flat)
         st["step"] += 1
-        E.adam_step(flat, grads, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"], g["eps"],
-                    g["weight_decay"], scale)
+        self._update(flat, grads, scale)
 
     def state_dict(self):
         return dict(state={k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()},
@@ -70,3 +70,26 @@ class FusedAdam:
     def load_state_dict(self, sd):
         self.state.update(sd["state"])
         self.param_groups[0].update(sd["param_groups"][0])
+
+
+class FusedAdam(_FlatOptimizer):
+    _buffers = ("exp_avg", "exp_avg_sq")
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None):
+        super().__init__(model, process_group, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def _update(self, flat, grads, scale):
+        g, st = self.param_groups[0], self.state
+        E.adam_step(flat, grads, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"], g["betas"], g["eps"],
+                    g["weight_decay"], scale)
+
+
+class FusedSGD(_FlatOptimizer):
+    _buffers = ("momentum_buffer",)
+
+    def __init__(self, model, lr=1e-3, momentum=0.0, weight_decay=0.0, process_group=None):
+        super().__init__(model, process_group, lr=lr, momentum=momentum, weight_decay=weight_decay)
+
+    def _update(self, flat, grads, scale):
+        g, st = self.param_groups[0], self.state
+        E.sgd_step(flat, grads, st["momentum_buffer"], st["step"], g["lr"], g["momentum"], g["weight_decay"], scale)

@@ -4,10 +4,11 @@
   save_normalizations :225-242  data_norm.json
   train / train_      :245-372  decay-on-plateau policy, best-validation-loss checkpoint, training_log.json
   train_swag          :375-516  SWAG statistics from swag_start_epoch on
-The loops are host glue; every step runs tu.train_step (forward tape, BPTT, BBB backward, fused Adam on the GPU).
-The reference reads its data with tu.load_HDF5(settings); HDF5 is out of scope here (h5py absent), so the
-loops take the two lists load_HDF5 would return -- `(X_normed[L, D] float32, target, ...)` tuples -- as arguments.
-`train_swag_finetune` is out of scope.  Loss plots are not drawn."""
+  train_swag_finetune :516-663  SGD(momentum 0.9, weight decay 1e-4) from a pre-trained state dict, SWAG statistics from epoch 0
+The loops are host glue; every step runs tu.train_step (forward tape, BPTT, BBB backward, fused Adam / SGD on the GPU).
+Like the reference they read their data with tu.load_HDF5(settings, test=False) (utils/data_utils.open_database: h5py
+when importable, the package's own reader otherwise); a caller that already holds the two lists load_HDF5 returns --
+`(X_normed[L, D] float32, target, ...)` tuples -- may pass them instead.  Loss plots are not drawn."""
 import json
 import os
 from time import time
@@ -21,8 +22,7 @@ from ..utils import training_utils as tu
 
 def _data(settings, list_data_train, list_data_val):
     if list_data_train is None or list_data_val is None:
-        raise ValueError("supernnova_amd.training.train_rnn takes the (train, val) lists of tu.load_HDF5 as arguments: "
-                         "the HDF5 reader is not part of this package")
+        return tu.load_HDF5(settings, test=False)                    # train_rnn.py:271, :387, :527
     return list_data_train, list_data_val
 
 
@@ -194,13 +194,48 @@ def train_swag(settings, list_data_train=None, list_data_val=None):
     return rnn, swag_rnn
 
 
+def train_swag_finetune(settings, list_data_train=None, list_data_val=None):
+    """SWAG fine-tuning (train_rnn.py:516-663): load `settings.swag_pretrained_path` into a fresh model, train it with
+    SGD (momentum 0.9, weight decay 1e-4 -- hard-coded in the reference, :541-546) for 30 epochs (:548-549), enter every
+    epoch's parameters into the SwagModel statistics and evaluate / save SWAG draws from the third epoch on.
+    The reference unpickles the pre-trained file (torch.load(..., weights_only=False), :537); here it must be a plain
+    state dict, read with weights_only=True.  Returns (rnn, swag_rnn)."""
+    from ..optim import FusedSGD
+    from ..utils.swag_utils import SwagModel
+    save_normalizations(settings)
+    list_data_train, list_data_val = _data(settings, list_data_train, list_data_val)
+    rnn = tu.get_model(settings, list_data_train[0][0].shape[1])
+    rnn.load_state_dict(torch.load(settings.swag_pretrained_path, map_location="cpu", weights_only=True))
+    criterion = nn.CrossEntropyLoss()
+    settings.swag_start_epoch = 0
+    settings.nb_epoch = 30
+    swag_rnn = SwagModel(rnn)
+    if settings.use_cuda:
+        rnn.cuda()
+        swag_rnn.cuda()
+    optimizer = FusedSGD(rnn, lr=settings.learning_rate, momentum=0.9, weight_decay=1e-4)
+    d_train, d_val = _monitors(settings)
+    best_loss, t_start = float("inf"), time()
+    for epoch in range(settings.nb_epoch):
+        _run_epoch(settings, rnn, criterion, optimizer, list_data_train)
+        if (epoch + 1) % settings.monitor_interval == 0:
+            _, _, best_loss = _monitor(settings, rnn, list_data_train, list_data_val, d_train, d_val, epoch, best_loss)
+        swag_rnn.update_parameters(rnn)
+        if epoch >= 2:
+            swag_rnn.last_metrics = tu.get_evaluation_metrics(settings, list_data_train, swag_rnn,
+                                                              sample_size=len(list_data_val), swag_sampling=True)
+            torch.save(swag_rnn.state_dict(),
+                       os.path.join(str(settings.rnn_dir), f"{settings.pytorch_model_name}_swag.pt"))
+    tu.save_training_results(settings, d_val, time() - t_start)
+    return rnn, swag_rnn
+
+
 def train(settings, list_data_train=None, list_data_val=None):
-    """Entry point of `snn train_rnn` (train_rnn.py:245-256 and cli/run.py:94-102); fine-tuning from a pre-trained
-    SWAG pickle (`train_swag_finetune`) is out of scope."""
-    if getattr(settings, "swag_pretrained_path", None):
-        raise ValueError("SWAG fine-tuning from a pickled model is not part of supernnova_amd")
+    """Entry point of `snn train_rnn` (train_rnn.py:245-256; the cyclic policy is chosen in cli/run.py:94-102)."""
     if getattr(settings, "swag", False):
         return train_swag(settings, list_data_train, list_data_val)
+    if getattr(settings, "swag_pretrained_path", None):
+        return train_swag_finetune(settings, list_data_train, list_data_val)
     if getattr(settings, "cyclic", False):
         return train_cyclic(settings, list_data_train, list_data_val)
     return train_(settings, list_data_train, list_data_val)

@@ -136,3 +136,52 @@ def test_train_swag_collects_statistics_and_predicts(tmp_path):
         probs = vr.predict_mc(fresh, [d[0] for d in test], 10).cpu().numpy()      # (N, 10, C), one launch
     target = np.array([d[1] for d in test])
     assert (np.median(probs, 1).argmax(1) == target).mean() > 0.85 and probs.std(1).max() > 0
+
+
+def test_fused_sgd_equals_torch_sgd():
+    """snn_sgd_step = torch.optim.SGD(momentum 0.9, weight_decay 1e-4) (train_rnn.py:541-546) over three steps."""
+    from supernnova_amd import engine as E
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(10_001, generator=g)
+    grads = [torch.randn(10_001, generator=g) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.SGD([ref], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    p, buf = p0.cuda(), torch.zeros(10_001, device="cuda")
+    for step, gr in enumerate(grads, start=1):
+        ref.grad = gr.double()
+        opt.step()
+        E.sgd_step(p, gr.cuda(), buf, step, 0.05, 0.9, 1e-4)
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=0)
+
+
+def test_train_swag_finetune_from_a_database_file(tmp_path):
+    """train(settings) with swag_pretrained_path set and NO lists: the loop reads <processed_dir>/database.h5 through
+    load_HDF5 (the package's reader; file written by tests/h5writer.py), loads the pre-trained state dict, runs the 30
+    SGD epochs of train_swag_finetune, collects one SWAG snapshot per epoch and leaves the reference's files."""
+    from h5writer import write_database
+    from test_h5reader import _file_db
+    from util import loader_settings
+    from supernnova_amd.training import train_rnn
+    from supernnova_amd.utils import training_utils as tu
+    out, _, feats = _file_db()
+    write_database(str(tmp_path / "database.h5"), out)
+    ls = loader_settings(feats)
+    st = _settings(tmp_path, "vanilla", swag_scale=0.5, swag_no_lr_cov=False)
+    st.__dict__.update({k: v for k, v in ls.__dict__.items() if k not in ("arr_norm",)})
+    st.arr_norm = ls.arr_norm
+    st.training_features_to_normalize = ls.training_features_to_normalize
+    st.processed_dir, st.batch_size, st.learning_rate, st.swag = str(tmp_path), 16, 1e-2, False
+    st.random_length = False             # the synthetic database holds curves of 1-2 epochs (random prefixes need >= 3)
+    np.random.seed(12)
+    torch.manual_seed(12)
+    pre = tu.get_model(st, len(st.training_features))
+    torch.save(pre.state_dict(), tmp_path / "pretrained.pt")
+    st.swag_pretrained_path = str(tmp_path / "pretrained.pt")
+    rnn, swag = train_rnn.train(st)
+    assert st.nb_epoch == 30 and st.swag_start_epoch == 0 and int(swag.n_averaged) == 30
+    log = json.load(open(tmp_path / "training_log.json"))[st.pytorch_model_name]
+    assert np.isfinite(log["loss"]) and set(swag.last_metrics) >= {"loss", "AUC", "Acc"}
+    moved = max(float((a.detach().cpu() - b.detach()).abs().max()) for a, b in zip(rnn.parameters(), pre.parameters()))
+    assert moved > 1e-3
+    for f in (f"{st.pytorch_model_name}.pt", f"{st.pytorch_model_name}_swag.pt", "data_norm.json"):
+        assert os.path.isfile(tmp_path / f), f

@@ -193,8 +193,9 @@ def test_plateau_loss_string_schedule_and_training_log(tmp_path):
     assert log["m1"]["AUC"] == 0.9 and log["m1"]["Acc"] == 0.75 and log["m1"]["loss"] == 0.4
     assert log["m1"]["training_time"] == 12.5 and log["m2"]["AUC"] == -1 and log["m2"]["loss"] == 0.9
 
-    with pytest.raises(ValueError):
-        train_rnn.train(settings())          # no data lists: the HDF5 reader is not part of the package
+    with pytest.raises(FileNotFoundError):   # no data lists: the loop reads <processed_dir>/database.h5 like the reference
+        train_rnn.train(settings(processed_dir=str(tmp_path / "nowhere"), rnn_dir=str(tmp_path), source_data="photometry",
+                                 training_features_to_normalize=[], arr_norm=np.zeros((0, 3))))
 
 
 def test_prediction_dataframes_match_the_reference_layout():
