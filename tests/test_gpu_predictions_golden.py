@@ -158,3 +158,43 @@ def test_multi_prefix_launch_equals_one_launch_per_slice(model):
         assert np.array_equal(got[inb], pr.cpu().numpy())
     assert np.array_equal(d_pred["all"], multi[0][1].cpu().numpy())
     assert np.isfinite(d_pred["all_sin"]).all() and np.isfinite(d_mfe["all_reverse"]).all()
+
+
+def test_early_prediction_per_time_step_in_one_launch():
+    """f2, early_prediction.get_predictions (visualization/early_prediction.py:19-81): the per-time-step loop of one light
+    curve as ONE launch over its T prefixes.  Vanilla: every prefix equals the reference's calling convention -- the dense
+    un-packed slice X[:i] expanded to a batch -- through the module's forward, to the probability bar; Bayesian /
+    variational: (T, S, C) with the percentiles of :72-79, the last prefix distributed like the full curve."""
+    import os
+    import util
+    from supernnova_amd.visualization import early_prediction as ep
+    z = dict(np.load(os.path.join(util.GOLDEN, "g10_predictions.npz")))
+    models = {}
+    for m in ("vanilla", "variational", "bayesian"):
+        _, st, data, rnn = _setup_flat(z, m)
+        rnn.draws = "philox"
+        models[f"{m}_S_0_CLF_2"] = rnn
+    st.num_inference_samples = 64
+    k = int(np.argmax(z["lengths"]))
+    X, target = data[k][0], data[k][1]
+    torch.manual_seed(3)
+    d_pred, X_out = ep.get_predictions(st, models, X, target)
+    T = X.shape[0]
+    assert np.array_equal(X_out, X) and set(d_pred) == set(models)
+    van = models["vanilla_S_0_CLF_2"]
+    with torch.no_grad():
+        Xt = torch.from_numpy(X).to(DEV)[:, None, :]
+        want = np.stack([torch.softmax(van(Xt[:i].expand(i, 1, X.shape[1])), -1).cpu().numpy() for i in range(1, T + 1)])
+    got = d_pred["vanilla_S_0_CLF_2"]["prob"]
+    assert got.shape == (T, 1, 2)
+    assert (np.abs(got - want) / want).max() < util.PROB_RTOL
+    for name in ("variational_S_0_CLF_2", "bayesian_S_0_CLF_2"):
+        d = d_pred[name]
+        assert d["prob"].shape == (T, 64, 2) and d["prob"].std(1).min() > 0
+        np.testing.assert_allclose(d["prob"].sum(-1), 1.0, atol=1e-6)
+        assert np.array_equal(d["median"], np.median(d["prob"], 1))
+        assert np.array_equal(d["perc_16"], np.percentile(d["prob"], 16, axis=1))
+        assert (d["perc_2"] <= d["perc_16"]).all() and (d["perc_84"] <= d["perc_98"]).all()
+    # an out-of-distribution transform goes through get_data_batch as in the reference (:23)
+    d_rev, X_rev = ep.get_predictions(st, {"vanilla_S_0_CLF_2": van}, X, target, OOD="reverse")
+    assert not np.array_equal(X_rev, X) and d_rev["vanilla_S_0_CLF_2"]["prob"].shape == (T, 1, 2)
