@@ -109,10 +109,14 @@ def allreduce_mean_scale(flat, group=None, producer_stream=None):
         if flat.is_cuda and producer_stream is not None and producer_stream != torch.cuda.current_stream(flat.device):
             torch.cuda.current_stream(flat.device).wait_stream(producer_stream)
         if flat.is_cuda and dist.get_backend(group) == "gloo" and not os.environ.get("SNN_DP_GLOO_DEVICE"):
-            # gloo (CPU rehearsal of the multi-rank path with ranks sharing a GPU) has no device data path of its own:
-            # ProcessGroupGloo stages device tensors through pinned host buffers it allocates PER CALL.  Staging the
-            # 320 KB buffer ourselves is the same data movement without that per-call allocation (DESIGN.md 5 has the
-            # measurement).  .cpu() synchronises with the current stream, copy_ is enqueued on it.
+            # gloo (rehearsal of the multi-rank path with ranks sharing a GPU).  ProcessGroupGloo's device-tensor path
+            # (a private stream that waits on an event of the current stream, pinned staging, a worker thread) stalls
+            # when two processes share one GPU and the producer of the tensor is still in flight at the call: a few
+            # rounds pass, then one takes seconds, then both ranks sit in all_reduce for good.  It does so WITHOUT any
+            # kernel of this library (torch matmul + pinned upload + all_reduce: microbench/gloo_stall_variants.py
+            # `heavy`), and it does not when the current stream is synchronised before the call (`step_sync`); records in
+            # profiles/r2/gloo_stall_variants.txt.  .cpu() below is that synchronisation plus the staging copy gloo
+            # would do itself; copy_ is enqueued on the current stream.  The RCCL path (else branch) is not involved.
             h = flat.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
             flat.copy_(h)
