@@ -175,7 +175,7 @@ def end_to_end(E, cfg, x, lengths, lengths_host, mu, rho, prior, S, steps, dev):
 
 def cpu_baseline_full(cfg, x, lengths_host, mu, rho, S):
     """BASELINE.md 3 protocol (minutes of CPU work; --cpu-full only): 12 800 curves = 100 batches of 128, median of 3
-    runs on all host threads this process was given, plus a 1-thread figure on 1 280 curves."""
+    runs on all host threads this process was given, plus the same protocol on 1 thread."""
     out = {"unit": "light curves/s", "kind": "port"}
     n = 12800
     xh, lh = x[:, :n].cpu().numpy(), lengths_host[:n]
@@ -187,9 +187,13 @@ def cpu_baseline_full(cfg, x, lengths_host, mu, rho, S):
         print(f"cpu baseline (full): run {r}: {v:.1f} curves/s in {secs:.0f} s on {threads} threads", file=sys.stderr, flush=True)
     out.update(value=float(np.median(runs)), runs=runs, cores=threads, sample=f"{n} curves, median of 3")
     torch.set_num_threads(1)
-    v1, secs = cpu_baseline(cfg, xh[:, :1280], lh[:1280], mu, rho, S, 1280)
+    runs1 = []
+    for r in range(3):
+        v1, secs = cpu_baseline(cfg, xh, lh, mu, rho, S, n)
+        runs1.append(v1)
+        print(f"cpu baseline (full): run {r}: {v1:.1f} curves/s in {secs:.0f} s on 1 thread", file=sys.stderr, flush=True)
     torch.set_num_threads(threads)
-    out["one_thread"] = {"value": v1, "cores": 1, "sample": f"1280 curves, {secs:.0f} s"}
+    out["one_thread"] = {"value": float(np.median(runs1)), "runs": runs1, "cores": 1, "sample": f"{n} curves, median of 3"}
     return out
 
 
@@ -456,14 +460,26 @@ def main():
             n_cpu = min(args.cpu_curves, N)
             if big and args.cpu_curves == 3840:
                 n_cpu = 128       # one reference batch: 300 steps at H=128 x 50 forwards is already tens of seconds of CPU work
-            print(f"cpu baseline: {n_cpu} curves on {torch.get_num_threads()} threads ...", file=sys.stderr, flush=True)
-            v, secs = (cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], flat_unscaled, None, S, n_cpu,
-                                    model="variational") if var else
-                       cpu_baseline(cfg, x[:, :n_cpu].cpu().numpy(), lengths_host[:n_cpu], mu, rho, S, n_cpu))
-            out["cpu_baseline"] = {"value": v, "unit": "light curves/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
+            run_cpu = (lambda n: cpu_baseline(cfg, x[:, :n].cpu().numpy(), lengths_host[:n], flat_unscaled, None, S, n,
+                                              model="variational")) if var else \
+                      (lambda n: cpu_baseline(cfg, x[:, :n].cpu().numpy(), lengths_host[:n], mu, rho, S, n))
+            # The reference runs with torch's default thread count (all cores); on many-core hosts the small per-step
+            # matmuls of a 128-curve batch run FASTER on one thread, so both settings are probed on a few batches and
+            # the sample is timed with the faster one: the baseline is the port at its best, not at its default.
+            all_threads = torch.get_num_threads()
+            probe, n_probe = {}, min(n_cpu, 128 if big else 640)
+            for th in sorted({1, all_threads}):
+                torch.set_num_threads(th)
+                probe[th] = run_cpu(n_probe)[0]
+                print(f"cpu baseline probe: {probe[th]:.1f} curves/s on {th} thread(s) ({n_probe} curves)", file=sys.stderr, flush=True)
+            best = max(probe, key=probe.get)
+            torch.set_num_threads(best)
+            v, secs = run_cpu(n_cpu)
+            torch.set_num_threads(all_threads)
+            out["cpu_baseline"] = {"value": v, "unit": "light curves/s", "cores": best, "kind": "port",
                                    "sample": f"first {n_cpu} curves of the same workload, batches of 128 x {S} "
-                                             f"sequential forwards (reference call pattern), {secs:.1f} s"}
+                                             f"sequential forwards (reference call pattern), {secs:.1f} s; thread probe on "
+                                             f"{n_probe} curves: " + ", ".join(f"{t} thread(s) {r:.0f}/s" for t, r in sorted(probe.items()))}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
