@@ -132,7 +132,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    assert bool(torch.isfinite(loss))
+    assert bool(torch.isfinite(loss)) or bool(os.environ.get("SNN_BENCH_NOCHECK"))      # (timing-ablation builds produce garbage)
     # phase times of the fused step (HIP events on the launch stream between the C-ABI calls), a few extra steps
     phases = None
     if args.path == "fused":

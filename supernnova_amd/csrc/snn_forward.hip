@@ -775,10 +775,15 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     p.nbuf = g.nbuf;
     p.tape = tape; p.tape_tile = tape_tile;
     hipStream_t st = (hipStream_t)stream;
-    // small training batches: one launch per layer with the two directions side by side (snn_fwd_small.h)
+    // training: one launch per layer, a workgroup per (tile, direction) (snn_fwd_small.h).  Written for small batches
+    // (it halves their latency chain), it is also the fastest path at every larger size measured (forward ms, one-tile
+    // persistent / two-tile persistent / layer-wise: 12 288 curves 0.54 / 0.61 / 0.32; 32 768: 0.84 / 1.07 / 0.69;
+    // 65 536: 1.55 / 1.40 / 1.30; 131 072: 3.06 / 2.72 / 2.63): independent workgroups leave the balancing to the
+    // dispatcher and run the two directions side by side.  The persistent kernel remains for unidirectional models,
+    // the GRU / tanh-RNN cells and batches whose head partials do not fit the workspace.
     const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * y.NW * y.C * 32;
-    static const bool no_layerwise = getenv("SNN_NO_LAYERWISE") != nullptr;   // A/B measurements only
-    if (train && e->fn_train_layer && !no_layerwise && n_tiles * y.dirs <= 2 * g.cus && 256 + part_bytes <= workspace_bytes) {
+    const bool no_layerwise = getenv("SNN_NO_LAYERWISE") != nullptr;   // A/B measurements and tests (read per call)
+    if (train && e->fn_train_layer && !no_layerwise && 256 + part_bytes <= workspace_bytes) {
         float* head_part = (float*)((char*)workspace + 256);
         HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_train_layer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
         for (int l = 0; l < y.L; ++l)

@@ -208,11 +208,16 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             outv[u] = valid ? hv : 0.0f;
             hn[u * 32] = hst[u];
             if (TRAIN) {
+#ifdef SNN_ABL_NOTAPE   // timing ablation only (the backward then reads garbage): what the gate / cell tape stores cost
+                if (p.n_curves < 0)
+#endif
+                {
                 tp[(0 * H + u) * 32] = ig;
                 tp[(1 * H + u) * 32] = fg;
                 tp[(2 * H + u) * 32] = gg;
                 tp[(3 * H + u) * 32] = og;
                 tp[(4 * H + u) * 32] = cn;
+                }
                 tp[(5 * H + u) * 32] = outv[u];
             }
         }
@@ -282,8 +287,11 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     __syncthreads();  // also publishes this phase's y / tape stores to the workgroup
 }
 
+#ifndef SNN_TRAIN_OCC
+#define SNN_TRAIN_OCC 2
+#endif
 template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED, int CELL = 0>
-__global__ void __launch_bounds__(H * 8, ((TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) * 32 / H > 0 ? ((TRAIN || MASKED) ? 2 : SNN_FWD_WAVES) * 32 / H : 1)
+__global__ void __launch_bounds__(H * 8, ((TRAIN || MASKED) ? SNN_TRAIN_OCC : SNN_FWD_WAVES) * 32 / H > 0 ? ((TRAIN || MASKED) ? SNN_TRAIN_OCC : SNN_FWD_WAVES) * 32 / H : 1)
 lstm_fwd_kernel(const FwdParams p)
 {
     constexpr int NT = H * 8;
@@ -371,8 +379,16 @@ lstm_fwd_kernel(const FwdParams p)
 // below) and halves the chain.  Same run_phase, same tape; each phase's per-wave head partials go to `head_part`
 // ([tile][ld][NW][C][32]) and head_combine_kernel (snn_forward.hip) adds them in the persistent kernel's order, so
 // the logits are bit-identical to the one-launch path.
+#ifndef SNN_TRAIN_LAYER_OCC
+#define SNN_TRAIN_LAYER_OCC 2
+#endif
+#ifdef SNN_ABL_LAYER_UNMASKED   // timing ablation only: what the mask code of the MASKED instantiation costs an un-masked model
+#define SNN_LAYER_MASKED false
+#else
+#define SNN_LAYER_MASKED true
+#endif
 template <int H, int KKI0, int DIRS>
-__global__ void __launch_bounds__(H * 8, 2 * 32 / H > 0 ? 2 * 32 / H : 1)
+__global__ void __launch_bounds__(H * 8, SNN_TRAIN_LAYER_OCC * 32 / H > 0 ? SNN_TRAIN_LAYER_OCC * 32 / H : 1)
 lstm_fwd_train_layer_kernel(const FwdParams p, int l, float* __restrict__ head_part)
 {
     constexpr int NT = H * 8;
@@ -410,10 +426,10 @@ lstm_fwd_train_layer_kernel(const FwdParams p, int l, float* __restrict__ head_p
     __syncthreads();
     if (l == 0) {
         const int kA = d * BLK0;
-        run_phase<H, KKI0, DIRS, true, true, true>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
+        run_phase<H, KKI0, DIRS, true, true, SNN_LAYER_MASKED>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
     } else {
         const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-        run_phase<H, KKI1, DIRS, false, true, true>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
+        run_phase<H, KKI1, DIRS, false, true, SNN_LAYER_MASKED>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, xin, hb, part, logit, bl);
     }
     if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {   // this phase feeds the head: `part` holds its per-wave partials
         float* dst = head_part + ((int64_t)c.tile * (y.L * DIRS) + l * DIRS + d) * (NW * y.C * 32);

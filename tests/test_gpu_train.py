@@ -309,17 +309,23 @@ def test_layerwise_training_forward_is_bit_identical_to_the_persistent_kernel(po
     from supernnova_amd import engine as E
     from util import make_curves
     cfg = E.Config(24, 32, 2, True, C, pool)
-    n_small, n_big, T = 100, 8400, 30          # 4 tiles (layer-wise path) vs 263 tiles (tiles x 2 > 2 x 256 CUs: persistent kernel)
+    n_small, n_big, T = 100, 8400, 30          # 4 tiles (layer-wise path) vs 263 tiles through the persistent kernel
     x, lengths = make_curves(21, n_big, T, 24, min_len=1)
     lengths[:n_small] = np.maximum(lengths[:n_small], 2)
     w = np.random.default_rng(4).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
     wk = E.prepare_weights(cfg, _t(w))
     mk = (lambda: E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=77, mid_T=1)) if masked else (lambda: None)
+    import os
     out = []
     for n in (n_small, n_big):
         plan = E.Plan(cfg, lengths[:n], DEV)
         xp = E.pack_x(cfg, plan, _t(x[:, :n]))
-        logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
+        if n == n_big:
+            os.environ["SNN_NO_LAYERWISE"] = "1"          # the persistent kernel (read per call)
+        try:
+            logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
+        finally:
+            os.environ.pop("SNN_NO_LAYERWISE", None)
         dlog = torch.zeros_like(logits)
         dlog[:n_small] = torch.linspace(-1, 1, n_small * C, device=DEV).view(n_small, C)
         dflat = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk())
@@ -511,3 +517,46 @@ def test_gru_rnn_train_step_two_adam_steps(cell, tag, fused):
             bound = 1e-3 * np.minimum(2.0, (1 + 2 * it) * dg * 1e-8 / (gmag + 1e-8) ** 2) + 3e-7
             err = np.abs(v.cpu().numpy().astype(np.float64) - ref[k])
             assert (err <= bound).all(), (it, k, float(err.max()), float((err / bound).max()))
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_layerwise_and_persistent_training_forward_write_the_same_tape(masked):
+    """The training forward runs one launch per layer with a workgroup per (tile, direction) at every batch size (the
+    persistent kernel, SNN_NO_LAYERWISE=1, remains for what the layer-wise kernel does not cover).  At a size that fills
+    the chip several times over, logits, pooled features and every tape row the backward reads are bit-identical
+    between the two, and so are the gradients."""
+    import os
+    from supernnova_amd import engine as E
+    from util import make_curves
+    cfg = E.Config(24, 32, 2, True, 3, "mean")
+    n, T = 1031 * 32 - 5, 30
+    x, lengths = make_curves(23, n, T, 24, min_len=1)
+    w = np.random.default_rng(5).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    wk = E.prepare_weights(cfg, _t(w))
+    mk = (lambda: E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=78, mid_T=1)) if masked else (lambda: None)
+    plan = E.Plan(cfg, lengths, DEV)
+    xp = E.pack_x(cfg, plan, _t(x))
+    dlog = torch.linspace(-1, 1, n * 3, device=DEV).view(n, 3)
+    res = []
+    for persistent in (False, True):
+        if persistent:
+            os.environ["SNN_NO_LAYERWISE"] = "1"
+        try:
+            logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
+            dflat = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk())
+        finally:
+            os.environ.pop("SNN_NO_LAYERWISE", None)
+        res.append((logits, tape.clone(), dflat))
+    assert torch.equal(res[0][0], res[1][0])
+    n_tiles = plan.n_tiles
+    step = 6 * 32 * 32
+    per_tile = 4 * plan.max_T * step + cfg.F * 32
+    ta = res[0][1][: n_tiles * per_tile].view(n_tiles, per_tile)
+    tb = res[1][1][: n_tiles * per_tile].view(n_tiles, per_tile)
+    tile_T = torch.from_numpy(np.array(plan.tile_T, dtype=np.int64)).to(DEV)
+    rows_a = ta[:, : 4 * plan.max_T * step].view(n_tiles, 4, plan.max_T, step)
+    rows_b = tb[:, : 4 * plan.max_T * step].view(n_tiles, 4, plan.max_T, step)
+    live = (torch.arange(plan.max_T, device=DEV)[None, :] < tile_T[:, None])[:, None, :, None]
+    assert torch.equal(torch.where(live, rows_a, 0.0), torch.where(live, rows_b, 0.0))
+    assert torch.equal(ta[:, 4 * plan.max_T * step:], tb[:, 4 * plan.max_T * step:])          # pooled features
+    assert torch.equal(res[0][2], res[1][2])
