@@ -31,29 +31,6 @@
         }                                                                           \
     } while (0)
 
-struct Bwd2Params {
-    SnnLayout lay;
-    const float* xp;
-    const int32_t* len_sorted;
-    const int32_t* order;
-    const int32_t* tile_T;
-    const int64_t* tile_off;
-    int n_curves, n_tiles, max_T;
-    const float* wk;
-    MaskP mk;
-    const float* tape;
-    int64_t tape_tile;
-    const float* dlogits;
-    float* WT;                                      // transposed weight images
-    int64_t wt_hh[SNN_MAX_LD], wt_ih[SNN_MAX_LD];   // float offsets into WT
-    float* dfeat;                                   // [tile][F][32]
-    float* dG;                                      // [tile][dir][max_T][4H][32], the layer being processed
-    const float* dy_in;                             // [tile][dir][max_T][H][32]: d loss / d (outputs of this layer)
-    float* dy_out;                                  // same layout, for the layer below
-    float* slabs;                                   // [n_chunks][P]
-    float* dflat;
-    int accumulate;
-};
 
 constexpr int PAD = 33;   // LDS row stride of transposed-read images
 
