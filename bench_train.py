@@ -160,12 +160,14 @@ def main():
         f_fwd = float(lengths.astype(np.int64).sum()) * 16 * H * (Dw + 4 * H) + B * 4 * H * C
         PEAK = 157.3      # fp32 MFMA TFLOP/s (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
         if phases is not None:
-            gpu_ms = sum(phases.values())
-            ach = 3 * f_fwd / (gpu_ms * 1e-3) / 1e12
+            # achieved = this rank's algorithmic FLOPs per step / the step time of the TIMED loop (back-to-back steps: the
+            # host prepares step i + 1 while the GPU runs step i).  The phase times below come from separate steps with a
+            # synchronisation after each, so their sum is the latency of ONE isolated step, host gaps included.
+            ach = 3 * f_fwd / (dt / args.steps) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "whole fused step (phases below; per-kernel times: profiles/r2/)",
+                "bound": "mfma", "kernel": "whole fused step, timed loop (phases below: isolated steps; per-kernel times: profiles/r2/)",
                 "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK, "traffic": None,
-                "flop_per_step": 3 * f_fwd, "gpu_ms_per_step": gpu_ms,
+                "flop_per_step": 3 * f_fwd, "isolated_step_ms": sum(phases.values()),
                 "phases_ms": phases,
                 "forward": {"flop": f_fwd, "ms": phases.get("forward"),
                             "frac": f_fwd / (phases["forward"] * 1e-3) / 1e12 / PEAK},

@@ -187,6 +187,20 @@ int snn_pack_x(const snn_cfg *cfg, const float *x, int64_t stride_t, int64_t str
                const int64_t *tile_off, int32_t n_tiles, int64_t xp_floats, float *xp, void *stream);
 
 /*
+ * snn_pack_x for a source whose time steps are not equally spaced -- torch's PackedSequence.data, what
+ * get_data_batch hands the model (utils/training_utils.py:479; torch.nn.utils.rnn.pack_padded_sequence): step t
+ * holds batch_sizes[t] rows, the rows of the batch columns that are still running.  Row t of curve n is read at
+ *   x[step_off[t] + (curve_off ? curve_off[n] : n * stride_n) + k]
+ * with step_off (max_T, DEVICE) = D * sum(batch_sizes[:t]) and curve n in column n (stride_n = D) or, for a batch
+ * packed with enforce_sorted=False, in column unsorted_indices[n] (curve_off[n] = D * unsorted_indices[n]).
+ * Replaces pad_packed_sequence (vanilla_rnn.py:75-76) + snn_pack_x: no padded copy is made.
+ */
+int snn_pack_x_steps(const snn_cfg *cfg, const float *x, const int64_t *step_off, int64_t stride_n,
+                     const int64_t *curve_off, const int32_t *order, const int32_t *len_sorted,
+                     const int32_t *tile_T, const int64_t *tile_off, int32_t n_tiles, int64_t xp_floats,
+                     float *xp, void *stream);
+
+/*
  * Host-only: the row-building half of the on-the-fly (broker) featuriser (validation/validate_onthefly.py:65-120 ->
  * utils/data_utils.compute_delta_time :364-390, data/make_dataset.pivot_dataframe_single_from_df :800-938).
  * snn_featurize_plan: observations (curve index, MJD) -> `order` (sorted by curve, then MJD, stable), and for the j-th

@@ -64,6 +64,8 @@ SIGNATURES = {
     "snn_plan_build": (ctypes.c_int, [_CFG, _I32P, ctypes.c_int32, _I32P, _I32P, _I32P, _I64P]),
     "snn_pack_x": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int64, _P, _P, _P, _P, _P,
                                   ctypes.c_int32, ctypes.c_int64, _P, _P]),
+    "snn_pack_x_steps": (ctypes.c_int, [_CFG, _P, _P, ctypes.c_int64, _P, _P, _P, _P, _P,
+                                        ctypes.c_int32, ctypes.c_int64, _P, _P]),
     "snn_prepare_weights": (ctypes.c_int, [_CFG, _P, _P, _P]),
     "snn_prepare_weights_multi": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int32, _P, _P]),
     "snn_bbb_sample": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,

@@ -25,7 +25,7 @@
 // precision 2 (NPC == 2): the same image with two fp16 pieces (split2)
 template <int NPC>
 __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, const float* __restrict__ x,
-                                                     int64_t stride_t, int64_t stride_n,
+                                                     int64_t stride_t, const int64_t* __restrict__ step_off, int64_t stride_n,
                                                      const int64_t* __restrict__ curve_off,
                                                      const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ len_sorted,
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
         const int orig = order[pos];
         const bool live = orig >= 0 && t < len_sorted[pos];
         const int on = live ? orig : 0;
-        const float* src = x + (int64_t)t * stride_t + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
+        const float* src = x + (step_off ? step_off[t] : (int64_t)t * stride_t) + (curve_off ? (live ? curve_off[on] : 0) : (int64_t)on * stride_n);
         const int k0 = 16 * b + 8 * (lp >> 5);
         uint4* o = dst + (int64_t)t * step_u4 + (int64_t)b * NPC * 64 + lp;
         if (NPC == 3) {
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) pack_x3_kernel(int D, int Dp, int XB, con
 // contiguous).  PACK_TS time steps per barrier pair; dynamic LDS = PACK_TS * Dp * 33 floats.
 #define PACK_TS 4
 __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float* __restrict__ x,
-                                                    int64_t stride_t, int64_t stride_n,
+                                                    int64_t stride_t, const int64_t* __restrict__ step_off, int64_t stride_n,
                                                     const int64_t* __restrict__ curve_off,
                                                     const int32_t* __restrict__ order,
                                                     const int32_t* __restrict__ len_sorted,
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) pack_x_kernel(int D, int Dp, const float*
             const int tt = e / row, r = e - tt * row;
             const int c = r / D, k = r - c * D;
             const int t = t0 + tt;
-            pk_lds[(tt * Dp + k) * (SNN_TILE + 1) + c] = t < s_len[c] ? x[s_base[c] + (int64_t)t * stride_t + k] : 0.0f;
+            pk_lds[(tt * Dp + k) * (SNN_TILE + 1) + c] = t < s_len[c] ? x[s_base[c] + (step_off ? step_off[t] : (int64_t)t * stride_t) + k] : 0.0f;
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nt * img; e += blockDim.x) {
@@ -402,9 +402,9 @@ extern "C" int snn_plan_build(const snn_cfg* cfg, const int32_t* lengths, int32_
         }                                                                           \
     } while (0)
 
-extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, int64_t stride_n,
-                          const int64_t* curve_off, const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
-                          const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp, void* stream)
+static int pack_x_launch(const snn_cfg* cfg, const float* x, int64_t stride_t, const int64_t* step_off, int64_t stride_n,
+                         const int64_t* curve_off, const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
+                         const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp, void* stream)
 {
     SnnLayout y;
     int rc = snn_make_layout(cfg, &y);
@@ -424,16 +424,34 @@ extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, 
     }
     if (y.prec != 0) {
         hipLaunchKernelGGL(y.prec == 1 ? pack_x3_kernel<3> : pack_x3_kernel<2>, dim3(n_tiles), dim3(256), 0,
-                           (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t, stride_n, curve_off, order, len_sorted,
+                           (hipStream_t)stream, y.D, y.Dp, y.XB[0], x, stride_t, step_off, stride_n, curve_off, order, len_sorted,
                            tile_T, tile_off, reinterpret_cast<__bf16*>(xp), xp_floats);
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
     hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256),
                        sizeof(float) * PACK_TS * y.Dp * (SNN_TILE + 1), (hipStream_t)stream, y.D, y.Dp, x, stride_t,
-                       stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp, xp_floats);
+                       step_off, stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp, xp_floats);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
+}
+
+extern "C" int snn_pack_x(const snn_cfg* cfg, const float* x, int64_t stride_t, int64_t stride_n,
+                          const int64_t* curve_off, const int32_t* order, const int32_t* len_sorted, const int32_t* tile_T,
+                          const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp, void* stream)
+{
+    return pack_x_launch(cfg, x, stride_t, nullptr, stride_n, curve_off, order, len_sorted, tile_T, tile_off, n_tiles, xp_floats,
+                         xp, stream);
+}
+
+extern "C" int snn_pack_x_steps(const snn_cfg* cfg, const float* x, const int64_t* step_off, int64_t stride_n,
+                                const int64_t* curve_off, const int32_t* order, const int32_t* len_sorted,
+                                const int32_t* tile_T, const int64_t* tile_off, int32_t n_tiles, int64_t xp_floats, float* xp,
+                                void* stream)
+{
+    if (!step_off) { snn_set_error("snn_pack_x_steps: step_off is NULL"); return SNN_ERR_ARG; }
+    return pack_x_launch(cfg, x, 0, step_off, stride_n, curve_off, order, len_sorted, tile_T, tile_off, n_tiles, xp_floats, xp,
+                         stream);
 }
 
 static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, const float* eps, int mode,

@@ -132,8 +132,40 @@ class Plan:
         return self
 
 
+class PackedRows:
+    """The rows of a torch PackedSequence as snn_pack_x_steps reads them -- no padded copy:
+    data (sum(batch_sizes), D) fp32 on the GPU, step_off (T,) device int64 float offset of each step's first row,
+    col_off (B,) device int64 float offset of each curve's column inside a step (None: curve n is column n)."""
+
+    def __init__(self, data, step_off, col_off, n_curves):
+        self.data, self.step_off, self.col_off, self.n_curves = data, step_off, col_off, n_curves
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def is_cuda(self):
+        return self.data.is_cuda
+
+
 def pack_x(cfg, plan, x, time_major=True):
-    """x: (T,B,D) (time_major) or (B,T,D) padded fp32 on the GPU -> packed tile buffer."""
+    """x: (T,B,D) (time_major) or (B,T,D) padded fp32 on the GPU, or PackedRows -> packed tile buffer."""
+    if isinstance(x, PackedRows):
+        _require_cuda(x.data, "x.data")
+        D = cfg.input_size
+        if x.data.dim() != 2 or x.data.size(1) != D or x.n_curves != plan.n_curves or x.step_off.numel() < plan.max_T:
+            raise L.SnnError(f"packed rows {tuple(x.data.shape)} / {x.step_off.numel()} steps do not match the plan "
+                             f"(n_curves={plan.n_curves}, max_T={plan.max_T}, D={D})")
+        if x.data.size(0) != int(plan.lengths.astype(np.int64).sum()):
+            raise L.SnnError("packed rows do not hold sum(lengths) rows")
+        n_xp = plan.packed_floats(cfg)
+        xp = torch.empty(n_xp, dtype=torch.float32, device=x.data.device)
+        L.check(L.load().snn_pack_x_steps(ctypes.byref(cfg.c), _ptr(x.data), _ptr(x.step_off), D,
+                                          None if x.col_off is None else _ptr(x.col_off), _ptr(plan.d_order),
+                                          _ptr(plan.d_len_sorted), _ptr(plan.d_tile_T), _ptr(plan.d_tile_off), plan.n_tiles,
+                                          n_xp, _ptr(xp), _stream()), "snn_pack_x_steps")
+        return xp
     _require_cuda(x, "x")
     if x.dim() != 3 or x.size(-1) != cfg.input_size:
         raise L.SnnError(f"x must be 3-D with last dim {cfg.input_size}, got {tuple(x.shape)}")

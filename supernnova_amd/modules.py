@@ -71,34 +71,26 @@ class _WeightDropParams(nn.Module):
 
 
 def unpack_packed_sequence(x):
-    """pad_packed_sequence (vanilla_rnn.py:75-76) in three device operations instead of one copy per time step:
-    zeros, one host-built row map, one index_copy_.  Returns (padded (T, B, D) float32 in the original batch order,
-    lengths int32 numpy (B,) in the original order) -- the same values pad_packed_sequence returns."""
+    """What pad_packed_sequence (vanilla_rnn.py:75-76) is used for, without the padded copy: a PackedSequence's rows
+    stay where they are (engine.PackedRows: the data tensor, the offset of every time step, the column of every curve)
+    and snn_pack_x_steps reads them straight into the tile image.  Returns (PackedRows, lengths int32 numpy (B,) in the
+    original batch order -- the lengths pad_packed_sequence returns)."""
     bs = x.batch_sizes.numpy().astype(np.int64)
     T, B, D = bs.size, int(bs[0]), x.data.size(-1)
-    total = int(bs.sum())
-    if total > 32768:
-        # large batches: torch's T copies are bandwidth-bound and cheaper than building and uploading a row map
-        # (MI355X, T = 40, D = 24: 0.19 ms vs 0.31 ms at 8192 curves; 0.19 vs 0.04 ms at 128 curves the other way)
-        padded, lens = pad_packed_sequence(x)
-        return padded.float(), lens.numpy().astype(np.int32)
-    start = np.zeros(T, np.int64)
-    np.cumsum(bs[:-1], out=start[1:])
-    t_idx = np.repeat(np.arange(T, dtype=np.int64), bs)
-    b_idx = np.arange(total, dtype=np.int64) - start[t_idx]          # sorted position of each packed row
     lengths = np.searchsorted(-bs, -np.arange(B, dtype=np.int64), side="left").astype(np.int32)   # steps with bs > b
+    dev = x.data.device
+    col_off = None
     if x.sorted_indices is not None:
         si = x.sorted_indices.cpu().numpy()
-        b_idx = si[b_idx]
         lens = np.empty_like(lengths)
         lens[si] = lengths
         lengths = lens
-    rows_h = torch.empty(total, dtype=torch.int64, pin_memory=x.data.is_cuda)   # pinned: the upload does not block the host
-    np.add(t_idx * B, b_idx, out=rows_h.numpy())
-    rows = rows_h.to(x.data.device, non_blocking=True)
-    padded = torch.zeros((T * B, D), dtype=torch.float32, device=x.data.device)
-    padded.index_copy_(0, rows, x.data.float())
-    return padded.view(T, B, D), lengths
+        col_off = x.unsorted_indices.to(device=dev, dtype=torch.int64) * D
+    step_h = torch.empty(T, dtype=torch.int64, pin_memory=x.data.is_cuda)      # pinned: the upload does not block the host
+    so = step_h.numpy()
+    so[0] = 0
+    np.cumsum(bs[:-1] * D, out=so[1:])
+    return E.PackedRows(x.data.float().contiguous(), step_h.to(dev, non_blocking=True), col_off, B), lengths
 
 
 def _check_settings(settings, layer_types=("lstm",)):
@@ -213,7 +205,10 @@ class _HipRNN(nn.Module):
             if x.data.size(-1) != self.input_size:
                 raise RuntimeError("input.size(-1) must be equal to input_size. Expected {}, got {}".format(
                     self.input_size, x.data.size(-1)))
-            padded, lengths = unpack_packed_sequence(x)
+            if not x.data.is_cuda:
+                raise L.SnnError("supernnova_amd modules run on the GPU only: move the module and its input "
+                                 "to a HIP device (there is no CPU fallback)")
+            return unpack_packed_sequence(x)
         else:
             if x.dim() != 3:
                 raise RuntimeError(f"input must have 3 dimensions, got {x.dim()}")

@@ -628,3 +628,29 @@ def test_split_precision_pack_image_is_the_documented_layout(prec, D, N, T):
                     want[step_off[tile]:step_off[tile] + n, b, p, c + 32 * kh, e] = pieces[p][:n, o, k]
     got = E.pack_x(cfg, plan, _t(x)).view(torch.int16).cpu().numpy().reshape(want.shape)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+@pytest.mark.parametrize("enforce_sorted", [True, False])
+def test_pack_from_packed_sequence_rows_equals_pack_from_padded(prec, enforce_sorted):
+    """snn_pack_x_steps reads a PackedSequence's rows in place (step t at step_off[t], curve n in column
+    unsorted_indices[n]); the tile image is bit-identical to snn_pack_x over the padded tensor pad_packed_sequence
+    would have made -- 1 curve, a partial tile, several tiles; also through the modules (logits bit-identical)."""
+    from torch.nn.utils.rnn import pack_padded_sequence
+    from supernnova_amd import engine as E
+    from supernnova_amd.modules import unpack_packed_sequence
+    g = torch.Generator().manual_seed(5)
+    for B, T in [(1, 7), (33, 40), (700, 25)]:
+        cfg = E.Config(24, 32, 2, True, 2, "mean").with_precision(prec)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        if enforce_sorted:
+            lens = lens.sort(descending=True).values
+        lens[0 if enforce_sorted else int(torch.randint(0, B, (1,), generator=g))] = T
+        x = torch.randn(T, B, 24, generator=g)
+        for b in range(B):
+            x[lens[b]:, b] = 0
+        pk = pack_padded_sequence(x.to(DEV), lens, enforce_sorted=enforce_sorted)
+        rows, lengths = unpack_packed_sequence(pk)
+        assert np.array_equal(lengths, lens.numpy())
+        plan = E.Plan(cfg, lengths, DEV)
+        assert torch.equal(E.pack_x(cfg, plan, rows), E.pack_x(cfg, plan, x.to(DEV)))

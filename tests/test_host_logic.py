@@ -223,19 +223,31 @@ def test_prediction_dataframes_match_the_reference_layout():
 
 
 def test_unpack_packed_sequence_equals_pad_packed_sequence():
-    """The modules' PackedSequence unpacking (three device operations) returns what torch's pad_packed_sequence
-    (vanilla_rnn.py:75-76) returns: sorted and enforce_sorted=False inputs, single curve, single step."""
+    """The modules read a PackedSequence in place (engine.PackedRows -> snn_pack_x_steps): the lengths are those of
+    torch's pad_packed_sequence (vanilla_rnn.py:75-76), and row t of curve n addressed as the kernel addresses it
+    (step_off[t] + column offset) is pad_packed_sequence's [t, n]: sorted and enforce_sorted=False inputs, single curve,
+    single step."""
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     from supernnova_amd.modules import unpack_packed_sequence
     g = torch.Generator().manual_seed(0)
+    D = 6
     for trial, (B, T) in enumerate([(1, 1), (1, 9), (7, 1), (33, 40), (128, 40), (5, 3), (64, 17), (31, 29), (2000, 40), (2001, 40)]):
         lens = torch.randint(1, T + 1, (B,), generator=g)
-        x = torch.randn(T, B, 6, generator=g)
+        x = torch.randn(T, B, D, generator=g)
         srt = trial % 2 == 0
         if srt:
             lens = lens.sort(descending=True).values
         pk = pack_padded_sequence(x, lens, enforce_sorted=srt)
         ref, ref_lens = pad_packed_sequence(pk)
-        got, got_lens = unpack_packed_sequence(pk)
-        assert torch.equal(ref, got) and got.dtype == torch.float32
+        rows, got_lens = unpack_packed_sequence(pk)
         assert got_lens.dtype == np.int32 and np.array_equal(ref_lens.numpy(), got_lens)
+        assert rows.data.dtype == torch.float32 and rows.n_curves == B and (rows.col_off is None) == srt
+        flat = rows.data.reshape(-1).numpy()
+        step_off = rows.step_off.numpy()
+        col = np.arange(B) * D if rows.col_off is None else rows.col_off.numpy()
+        got = np.zeros_like(ref.numpy())
+        for n in range(B):
+            for t in range(int(got_lens[n])):
+                o = step_off[t] + col[n]
+                got[t, n] = flat[o:o + D]
+        assert np.array_equal(got, ref.numpy())
