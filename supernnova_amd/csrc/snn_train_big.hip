@@ -624,8 +624,8 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) nv.q[q][i] = tq[off_q[q][i]];
-                nv.q[5][i] = tqp[off_q[4][i]];
+                for (int q = 0; q < 4; ++q) nv.q[q][i] = tq[off_q[q][i]];
+                nv.q[5][i] = tqp[off_q[4][i]];        // c of the step before; the next step takes it over as ITS c (c_carry)
 #pragma unroll
                 for (int pd = 0; pd < DIRS; ++pd) nv.dy[pd][i] = (dyb + pd * dy_pstep)[off_dy[i]];
             }
@@ -668,6 +668,9 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 }
             }
         };
+        float c_carry[UPT];
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) c_carry[i] = T > 0 ? (tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts)[off_q[4][i]] : 0.0f;   // c of the first processed step
         auto do_step = [&](const int step, const StepVals& cv, StepVals& nv) {
             const int t = d == 0 ? step : T - 1 - step;
             const int tp = d == 0 ? t - 1 : t + 1;
@@ -691,7 +694,7 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 const int j = jg + 16 * i;
                 float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
                 if (valid) {
-                    const float ig = q_[0][i], fg = q_[1][i], gg = q_[2][i], og = q_[3][i], cn = q_[4][i];
+                    const float ig = q_[0][i], fg = q_[1][i], gg = q_[2][i], og = q_[3][i], cn = c_carry[i];
                     float dh = dhr[i] + dyv[i];
                     if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
                     const float cp = prev_live ? q_[5][i] : 0.0f;
@@ -708,6 +711,7 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 dGl[(2 * H + j) * SP + c] = dag;
                 dGl[(3 * H + j) * SP + c] = dao;
                 db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
+                c_carry[i] = q_[5][i];     // every c_t is read from the tape once: as the predecessor's c here, as its own c next step
             }
             flush_pend();          // the previous step's dy (the tape values of this step have landed: see above)
             __syncthreads();
