@@ -197,57 +197,10 @@ def cpu_baseline_full(cfg, x, lengths_host, mu, rho, S):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
-    ap.add_argument("--samples", type=int, default=50)
-    ap.add_argument("--max-len", type=int, default=40)
-    ap.add_argument("--workload", choices=["des", "elasticc", "variational"], default="des",
-                    help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
-                         "(H=128, 6 filters + redshift, 14 classes, 300-step sequences); variational: configs[1] "
-                         "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des) -- the last two "
-                         "are secondary measurements")
-    ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-selfcheck", action="store_true",
-                    help="skip the subset re-run after the timed region (profiling runs: keeps the kernel statistics to "
-                         "the timed launches)")
-    ap.add_argument("--no-end-to-end", action="store_true",
-                    help="skip the PCIe-inclusive measurement the default (f32, des, 1 GPU) run appends as `end_to_end`")
-    ap.add_argument("--cpu-full", action="store_true",
-                    help="also time the CPU port with the BASELINE.md 3 protocol (12 800 curves, median of 3, and 1 thread): "
-                         "several minutes of CPU work")
-    ap.add_argument("--no-fast-path", action="store_true",
-                    help="skip the extra f16x2 measurement the default (f32, des, 1 GPU) run appends as `fast_path`")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
-                    help="f32: every gate product in fp32 (default); bf16x3 / f16x2: each fp32 product rebuilt from six "
-                         "bf16 / three fp16 piece products on the 16-bit matrix pipe (include/snn_hip.h)")
-    args = ap.parse_args()
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: start one fresh process per GPU BEFORE anything here touches the GPU
-        from supernnova_amd.distributed import self_launch
-        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+def run(args, rank, world, dev, backend, dist):
+    """One workload: warm-up + timed steps + the derived objects of the JSON line (rank 0 returns the dict)."""
+    out = None
+    args = __import__("copy").copy(args)          # (the workload defaults below edit curves / max_len)
     from supernnova_amd import engine as E
 
     big = args.workload == "elasticc"
@@ -480,6 +433,79 @@ def main():
                                    "sample": f"first {n_cpu} curves of the same workload, batches of 128 x {S} "
                                              f"sequential forwards (reference call pattern), {secs:.1f} s; thread probe on "
                                              f"{n_probe} curves: " + ", ".join(f"{t} thread(s) {r:.0f}/s" for t, r in sorted(probe.items()))}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
+    ap.add_argument("--samples", type=int, default=50)
+    ap.add_argument("--max-len", type=int, default=40)
+    ap.add_argument("--workload", choices=["des", "elasticc", "variational"], default="des",
+                    help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
+                         "(H=128, 6 filters + redshift, 14 classes, 300-step sequences); variational: configs[1] "
+                         "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des) -- the last two "
+                         "are secondary measurements")
+    ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-selfcheck", action="store_true",
+                    help="skip the subset re-run after the timed region (profiling runs: keeps the kernel statistics to "
+                         "the timed launches)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the PCIe-inclusive measurement the default (f32, des, 1 GPU) run appends as `end_to_end`")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="also time the CPU port with the BASELINE.md 3 protocol (12 800 curves, median of 3, and 1 thread): "
+                         "several minutes of CPU work")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two secondary workloads (variational, elasticc) the default run appends as `secondary`")
+    ap.add_argument("--no-fast-path", action="store_true",
+                    help="skip the extra f16x2 measurement the default (f32, des, 1 GPU) run appends as `fast_path`")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
+                    help="f32: every gate product in fp32 (default); bf16x3 / f16x2: each fp32 product rebuilt from six "
+                         "bf16 / three fp16 piece products on the 16-bit matrix pipe (include/snn_hip.h)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU BEFORE anything here touches the GPU
+        from supernnova_amd.distributed import self_launch
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    out = run(args, rank, world, dev, backend, dist if world > 1 else None)   # (`dist` is bound above only when world > 1)
+    default_run = (args.workload == "des" and args.precision == "f32" and world == 1 and args.curves == 1_250_000 and
+                   not os.environ.get("SNN_BENCH_NOCHECK") and not args.no_secondary)
+    if default_run:
+        # the other single-GPU configurations of BASELINE.json (configs[1]: VariationalRNN MC dropout; configs[4]: the
+        # ELAsTiCC-like H = 128 / 300-step model), two timed steps each, so that the line the driver records carries them
+        import copy
+        out["secondary"] = {}
+        for wl in ("variational", "elasticc"):
+            a2 = copy.copy(args)
+            a2.workload, a2.steps, a2.warmup, a2.cpu_curves = wl, 2, 1, 0
+            a2.no_fast_path = a2.no_end_to_end = a2.no_selfcheck = True
+            a2.cpu_full = False
+            sub = run(a2, rank, world, dev, backend, None)
+            out["secondary"][wl] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline")}
+            out["secondary"][wl]["workload"] = sub["config"]["workload"]
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
