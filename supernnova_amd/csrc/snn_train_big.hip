@@ -614,60 +614,66 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
         }
         const float* x_base = FIRST ? xtile : tape + (int64_t)((l - 1) * DIRS) * p.max_T * ts + 5 * H * 32;
         const int64_t x_step = FIRST ? (int64_t)y.Dp * 32 : ts;
-        auto fetch = [&](int step, StepVals& nv) {
-            const int t = d == 0 ? step : T - 1 - step;
-            const int tpc = step > 0 ? (d == 0 ? t - 1 : t + 1) : t;      // clamped: step 0 has no predecessor
-            const float* tq = tape_ld + (int64_t)t * ts;
-            const float* tqp = tape_ld + (int64_t)tpc * ts;
-            const float* dyb = dy0 + (int64_t)t * dy_tstep;
-            const float* xb = x_base + (int64_t)t * x_step;
+        // One step's operands = NLD load instructions per thread; its dy output = NST stores.  They are issued one by one
+        // BETWEEN the matrix products of the step before (piece()): a wave pushes the 64 addresses of a memory instruction
+        // to the texture addresser in ~8-16 cycles, and with all 8 waves issuing their ~25 at the top of a step that
+        // queue was 1 300 cycles per step during which the matrix pipe idled (measured with clock64 probes).
+        struct FetchBase { const float *tq, *tqp, *dyb, *xb; int t; };
+        auto fetch_base = [&](int step) {
+            FetchBase fb;
+            fb.t = d == 0 ? step : T - 1 - step;
+            const int tpc = step > 0 ? (d == 0 ? fb.t - 1 : fb.t + 1) : fb.t;      // clamped: step 0 has no predecessor
+            fb.tq = tape_ld + (int64_t)fb.t * ts;
+            fb.tqp = tape_ld + (int64_t)tpc * ts;
+            fb.dyb = dy0 + (int64_t)fb.t * dy_tstep;
+            fb.xb = x_base + (int64_t)fb.t * x_step;
+            return fb;
+        };
+        constexpr int NQ = UPT * 5, NDY = UPT * DIRS, NXH = MYNT * 4, NLD = NQ + NDY + NXH, NST = FIRST ? 0 : MTX * 2;
+        constexpr int NPIECE = NLD + NST;
+        float pend[MTX * 2];
 #pragma unroll
-            for (int i = 0; i < UPT; ++i) {
+        for (int i = 0; i < MTX * 2; ++i) pend[i] = 0.0f;
+        int pend_t = -1;
+        // piece k < NLD: one load of step fb into nv; NLD <= k < NPIECE: one store of the dy the step before produced
+        // (st_base: its time slot; before a tile's first dy exists, the slot of the running step, which the same thread
+        // overwrites with the real value one step later)
+        auto piece = [&](int k, const FetchBase& fb, StepVals& nv, float* st_base) {
+            if (k < NQ) {
+                const int i = k / 5, q = k - 5 * i;
+                if (q < 4) nv.q[q][i] = fb.tq[off_q[q][i]];
+                else nv.q[5][i] = fb.tqp[off_q[4][i]];    // c of the step before; the next step takes it over as ITS c (c_carry)
+            } else if (k < NQ + NDY) {
+                const int kk = k - NQ, i = kk / DIRS, pd = kk - DIRS * i;
+                nv.dy[pd][i] = (fb.dyb + pd * dy_pstep)[off_dy[i]];
+            } else if (k < NLD) {
+                // [h_{prev} | x_t] rows of this lane's columns (this role's tiles), curves 16 hf .. 16 hf + 15
+                const int kk = k - NQ - NDY, m = kk >> 2, q = kk & 3, nt = T0 + m;
+                const float* src = (nt == 0 ? fb.tqp + 5 * H * 32 : fb.xb) + off_x[m];
+                f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);   // (h_prev of step 0: clamped address, never multiplied)
+                if (masked && nt > 0) {
+                    const int kcol = 32 * (nt - 1) + cl;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) nv.q[q][i] = tq[off_q[q][i]];
-                nv.q[5][i] = tqp[off_q[4][i]];        // c of the step before; the next step takes it over as ITS c (c_carry)
-#pragma unroll
-                for (int pd = 0; pd < DIRS; ++pd) nv.dy[pd][i] = (dyb + pd * dy_pstep)[off_dy[i]];
-            }
-            // [h_{prev} | x_t] rows of this lane's columns (this role's tiles), curves 16 hf .. 16 hf + 15
-#pragma unroll
-            for (int m = 0; m < MYNT; ++m) {
-                const int nt = T0 + m;
-                const float* src = (nt == 0 ? tqp + 5 * H * 32 : xb) + off_x[m];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);   // (h_prev of step 0: clamped address, never multiplied)
-                    if (masked && nt > 0) {
-                        const int k = 32 * (nt - 1) + cl;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = origs[16 * hf + 4 * q + e];
-                            if (o >= 0 && k < (FIRST ? y.D : DIRS * H))
-                                v[e] = __fmul_rn(FIRST ? mask_in(p.mk, 0, p.n_curves, y.D, o, k)
-                                                       : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = origs[16 * hf + 4 * q + e];
+                        if (o >= 0 && kcol < (FIRST ? y.D : DIRS * H))
+                            v[e] = __fmul_rn(FIRST ? mask_in(p.mk, 0, p.n_curves, y.D, o, kcol)
+                                                   : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, fb.t, o, kcol), v[e]);
                     }
-                    nv.xh[m][q] = v;
                 }
+                nv.xh[m][q] = v;
+            } else if (k < NPIECE) {
+                const int i = k - NLD, f = jg + 16 * i, dd = f / H, j = f - dd * H;
+                st_base[(int64_t)dd * p.max_T * H * 32 + j * 32 + c] = pend[i];
             }
         };
+        auto dy_slot = [&](int tt) { return dy_out_base + (int64_t)d * dy_dir + ((int64_t)tile * DIRS * p.max_T + tt) * H * 32; };
         // Columns of [h | x] beyond the input width hold a clamped (valid, finite) column's data: the dW columns they
         // produce are dropped at the write-out, so they need no select.
         // dy of the layer below is stored one step late: gfx9's vmcnt counts loads and stores together, so the wait for
         // the tape values at the top of a step also waits for every store issued before it -- a store issued at the end
         // of the previous step would put its full round trip on the chain.  Issued after that wait instead, it has a
         // whole step to complete.
-        float pend[MTX * 2];
-        int pend_t = -1;
-        auto flush_pend = [&]() {
-            if (!FIRST && pend_t >= 0) {
-#pragma unroll
-                for (int i = 0; i < MTX * 2; ++i) {
-                    const int f = jg + 16 * i, dd = f / H, j = f - dd * H;
-                    dy_out_base[(int64_t)d * dy_dir + (((int64_t)tile * DIRS + dd) * p.max_T + pend_t) * H * 32 + j * 32 + c] = pend[i];
-                }
-            }
-        };
         float c_carry[UPT];
 #pragma unroll
         for (int i = 0; i < UPT; ++i) c_carry[i] = T > 0 ? (tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts)[off_q[4][i]] : 0.0f;   // c of the first processed step
@@ -685,9 +691,6 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 if (DIRS == 2) dyv[i] += cv.dy[DIRS - 1][i];
                 if (!has_dy) dyv[i] = 0.0f;
             }
-#ifndef SNN_ABL_STREAM_NOLOADS      // timing ablation only (results are wrong): the step without its global loads
-            if (step > 0) fetch(step - 1, nv);
-#endif
             // ---- gate gradients of this thread's 2 units (curve c)
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
@@ -713,9 +716,17 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
                 c_carry[i] = q_[5][i];     // every c_t is read from the tape once: as the predecessor's c here, as its own c next step
             }
-            flush_pend();          // the previous step's dy (the tape values of this step have landed: see above)
             __syncthreads();
-#ifndef SNN_ABL_STREAM_NOMFMA       // timing ablation only (results are wrong): the step without its matrix products
+            // ---- the matrix products of this step, with the loads of the next step (clamped at the tile's last step: the
+            // values are then unused) and the stores of the previous step's dy dealt out between them
+            const FetchBase fb = fetch_base(step > 0 ? step - 1 : 0);
+            float* st_base = FIRST ? nullptr : dy_slot(pend_t >= 0 ? pend_t : t);
+            constexpr int NSLOT = ((DO_REC || DO_DX) ? 16 : 0) + (MYNT > 0 ? 16 : 0);
+            auto slot = [&](int sl) {      // the pieces of slot sl, pinned behind the products issued so far
+#pragma unroll
+                for (int k = (sl * NPIECE) / NSLOT; k < ((sl + 1) * NPIECE) / NSLOT; ++k) piece(k, fb, nv, st_base);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             // ---- dh_{prev} (role 0) / dy of the layer below (role 1): K = this SIMD's 32 gate rows
             if (DO_REC || DO_DX) {
                 f32x16 ax[DO_DX ? MTX : 1];
@@ -732,6 +743,7 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
 #pragma unroll
                         for (int mt = 0; mt < MTX; ++mt) ax[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aih[mt][kk], bv, ax[mt], 0, 0, 0);
                     }
+                    slot(kk);
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -755,15 +767,12 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                         for (int m = 0; m < MYNT; ++m)
                             if (!(decltype(skip0)::value && T0 + m == 0))
                                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xh[m][kk >> 2][kk & 3], acc[m], 0, 0, 0);
+                        slot(((DO_REC || DO_DX) ? 16 : 0) + kk);
                     }
                 };
                 if (ROLE == 0 && step == 0) dw(std::true_type{});
                 else dw(std::false_type{});
             }
-#else
-#pragma unroll
-            for (int m = 0; m < MYNT; ++m) acc[m][0] += dGl[tid] * xh[m][0][0] + xh[m][1][1] + xh[m][2][2] + xh[m][3][3];
-#endif
             __syncthreads();
             if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
 #pragma unroll
@@ -785,14 +794,22 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 pend_t = t;
             }
         };
-        if (T > 0) fetch(T - 1, setA);
+        if (T > 0) {
+            const FetchBase fb0 = fetch_base(T - 1);
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) piece(k, fb0, setA, nullptr);
+        }
         int step = T - 1;
         for (; step >= 1; step -= 2) {
             do_step(step, setA, setB);
             do_step(step - 1, setB, setA);
         }
         if (step == 0) do_step(0, setA, setB);
-        flush_pend();
+        if (!FIRST && pend_t >= 0) {           // the dy of the tile's last step
+            float* st_last = dy_slot(pend_t);
+#pragma unroll
+            for (int k = NLD; k < NPIECE; ++k) piece(k, FetchBase{}, setA, st_last);
+        }
     }
 
     // ---- this workgroup's partial sums -> its slab (canonical layout, only the (layer, direction) slices it owns)
