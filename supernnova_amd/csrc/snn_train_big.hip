@@ -556,6 +556,10 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
 #pragma unroll
     for (int i = 0; i < 4 * UPT; ++i) db[i] = 0.0f;
 
+#ifdef SNN_PROBE_STREAM
+    long long probe[6] = {0, 0, 0, 0, 0, 0};
+    const long long pk0 = clock64();
+#endif
     for (int band = 0;; ++band) {
         const int tile = band * G + ((band & 1) ? G - 1 - g : g);
         if (band * G >= p.n_tiles) break;
@@ -678,6 +682,9 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
 #pragma unroll
         for (int i = 0; i < UPT; ++i) c_carry[i] = T > 0 ? (tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts)[off_q[4][i]] : 0.0f;   // c of the first processed step
         auto do_step = [&](const int step, const StepVals& cv, StepVals& nv) {
+#ifdef SNN_PROBE_STREAM     // measurement build (microbench/build_variant.sh probe -DSNN_PROBE_STREAM): cycles per phase of workgroup 0
+            const long long pt0 = clock64();
+#endif
             const int t = d == 0 ? step : T - 1 - step;
             const int tp = d == 0 ? t - 1 : t + 1;
             const bool valid = t < len;
@@ -716,7 +723,13 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 db[0 * UPT + i] += dai; db[1 * UPT + i] += daf; db[2 * UPT + i] += dag; db[3 * UPT + i] += dao;
                 c_carry[i] = q_[5][i];     // every c_t is read from the tape once: as the predecessor's c here, as its own c next step
             }
+#ifdef SNN_PROBE_STREAM
+            const long long pt1 = clock64();
+#endif
             __syncthreads();
+#ifdef SNN_PROBE_STREAM
+            const long long pt2 = clock64();
+#endif
             // ---- the matrix products of this step, with the loads of the next step (clamped at the tile's last step: the
             // values are then unused) and the stores of the previous step's dy dealt out between them
             const FetchBase fb = fetch_base(step > 0 ? step - 1 : 0);
@@ -773,7 +786,13 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 if (ROLE == 0 && step == 0) dw(std::true_type{});
                 else dw(std::false_type{});
             }
+#ifdef SNN_PROBE_STREAM
+            const long long pt3 = clock64();
+#endif
             __syncthreads();
+#ifdef SNN_PROBE_STREAM
+            const long long pt4 = clock64();
+#endif
             if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
 #pragma unroll
                 for (int i = 0; i < UPT; ++i) {
@@ -793,6 +812,10 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
                 }
                 pend_t = t;
             }
+#ifdef SNN_PROBE_STREAM
+            const long long pt5 = clock64();
+            probe[0] += pt1 - pt0; probe[1] += pt2 - pt1; probe[2] += pt3 - pt2; probe[3] += pt4 - pt3; probe[4] += pt5 - pt4; probe[5] += 1;
+#endif
         };
         if (T > 0) {
             const FetchBase fb0 = fetch_base(T - 1);
@@ -812,6 +835,12 @@ __device__ __forceinline__ void bwd_stream_role(const Bwd2Params& p, int l, int 
         }
     }
 
+#ifdef SNN_PROBE_STREAM
+    if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)
+        printf("probe l=%d role=%d steps=%lld  algebra %lld  barrier1 %lld  products %lld  barrier2 %lld  reduce %lld  per step; loop total %lld per step\n",
+               l, ROLE, probe[5], probe[0] / probe[5], probe[1] / probe[5], probe[2] / probe[5], probe[3] / probe[5], probe[4] / probe[5],
+               (clock64() - pk0) / probe[5]);
+#endif
     // ---- this workgroup's partial sums -> its slab (canonical layout, only the (layer, direction) slices it owns)
     float* slab = p.slabs + (int64_t)blockIdx.x * y.P;
     const int I = y.I[l];
