@@ -966,6 +966,16 @@ int64_t snn_bwd_stream_workspace_bytes(const SnnLayout& y, int n_tiles, int max_
     return rc ? rc : g.total_bytes;
 }
 
+#include "snn_bwd_stream3.h"
+
+template <int DIRS, bool MASKED>
+static bwd_stream_t stream3_kernel(int ntx, bool first)
+{
+    if (first) return ntx == 1 ? bwd_stream3_kernel<1, true, DIRS, MASKED> : ntx == 2 ? bwd_stream3_kernel<2, true, DIRS, MASKED>
+                                                                                    : bwd_stream3_kernel<3, true, DIRS, MASKED>;
+    return bwd_stream3_kernel<DIRS, false, DIRS, MASKED>;
+}
+
 template <int DIRS, bool MASKED>
 static bwd_stream_t stream_kernel(int ntx, bool first)
 {
@@ -1011,10 +1021,14 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
         const bool first = l == 0;
         const int ntx = first ? (y.Dp + 31) / 32 : y.dirs;
         const bool masked = mk.mode != SNN_MASK_NONE;
+        const bool v3 = getenv("SNN_STREAM3") != nullptr;
         bwd_stream_t fn = y.dirs == 2 ? (masked ? stream_kernel<2, true>(ntx, first) : stream_kernel<2, false>(ntx, first))
                                       : (masked ? stream_kernel<1, true>(ntx, first) : stream_kernel<1, false>(ntx, first));
+        if (v3)
+            fn = y.dirs == 2 ? (masked ? stream3_kernel<2, true>(ntx, first) : stream3_kernel<2, false>(ntx, first))
+                             : (masked ? stream3_kernel<1, true>(ntx, first) : stream3_kernel<1, false>(ntx, first));
         const int mtx = first ? 0 : y.dirs;
-        const size_t lds = sizeof(float) * ((size_t)4 * 32 * 33 + 4 * 32 * 32 + (size_t)4 * mtx * 32 * 32 + 32);
+        const size_t lds = sizeof(float) * ((size_t)(v3 ? 2 : 1) * 4 * 32 * 33 + 4 * 32 * 32 + (size_t)4 * mtx * 32 * 32 + 32);
         HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         float* dy_out = (l & 1) ? dyA : dyB;          // written by layer l for layer l - 1
         const float* dy_in = (l & 1) ? dyB : dyA;     // written by layer l + 1
