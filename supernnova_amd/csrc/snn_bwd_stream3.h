@@ -33,7 +33,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
     float* dGl = smem;                        // [2][4H][33]
     float* red = dGl + 2 * 4 * H * SP;        // [4 SIMDs][H][32]
     float* red2 = red + 4 * H * 32;           // [4 SIMDs][MTX * 32][32]
-    int* origs = reinterpret_cast<int*>(red2 + (FIRST ? 0 : 4 * MTX * 32 * 32));   // [32]
+    int* origs_lds = reinterpret_cast<int*>(red2 + (FIRST ? 0 : 4 * MTX * 32 * 32));   // [2][32]: this tile's curves, the next tile's
     const SnnLayout& y = p.lay;
     const int d = blockIdx.x / G, g = blockIdx.x - d * G;
     const int ld = l * DIRS + d;
@@ -58,11 +58,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             for (int kk = 0; kk < 16; ++kk) aih[mt][kk] = B[kk * 64];
         }
     }
-#ifndef SNN_S3_PRIO
-#define SNN_S3_PRIO 0
-#endif
-    if (SNN_S3_PRIO == 1 && ROLE == 1) __builtin_amdgcn_s_setprio(1);
-    if (SNN_S3_PRIO == 3 && ROLE == 0) __builtin_amdgcn_s_setprio(1);
+    // (s_setprio 1 for either role, or for role 1 during phase Q only: no measurable difference)
     f32x16 acc[MYNT > 0 ? MYNT : 1];
 #pragma unroll
     for (int nt = 0; nt < MYNT; ++nt)
@@ -76,89 +72,170 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
     long long probe[5] = {0, 0, 0, 0, 0}, pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long pk0 = clock64();
 #endif
-    for (int band = 0;; ++band) {
-        const int tile = band * G + ((band & 1) ? G - 1 - g : g);
-        if (band * G >= p.n_tiles) break;
-        if (tile >= p.n_tiles) continue;
-        const int T = __builtin_amdgcn_readfirstlane(p.tile_T[tile]);
-        if (T < 1) continue;
-        const int len = p.len_sorted[tile * SNN_TILE + c];
-        const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
-        const float* tape = p.tape + (int64_t)tile * p.tape_tile;
-        const float* tape_ld = tape + (int64_t)ld * p.max_T * ts;
-        const float* dfeat = p.dfeat + (int64_t)tile * y.F * 32;
-        const float* xtile = p.xp + p.tile_off[tile];
-        const float* dy_in = last_layer ? nullptr : dy_in_base + ((int64_t)tile * DIRS + d) * p.max_T * H * 32;
-        __syncthreads();                       // previous tile done with LDS
-        if (tid < 32) origs[tid] = p.order[tile * SNN_TILE + tid];
-        __syncthreads();
-
-        float dc[UPT], dhr[UPT], dfm[UPT];
+    // gate values (q 0-3: i, f, g, o; q 5: c of the step before -- each c_t is read once and carried) and dy of one
+    // step; [h | x] operand rows of one step.  Two of each, alternating: the step loop is unrolled by two.
+    struct QSet { float q[6][UPT], dy[DIRS][UPT]; };
+    struct XSet { f32x4 xh[MYNT > 0 ? MYNT : 1][4]; };
+    QSet qA, qB;
+    XSet xA, xB;
+    const bool has_dy = !last_layer;
+    const int64_t dy_tstep = has_dy ? (int64_t)H * 32 : 0, dy_pstep = has_dy ? dy_dir : 0;
+    // element (hidden unit jg + 16 i, curve c) of a [H][32] block: one per-lane offset, the rest goes into the (scalar) base
+    const unsigned off0 = (unsigned)(jg * 32 + c);
+    unsigned off_x[MYNT > 0 ? MYNT : 1];
 #pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 16 * i;
-            dc[i] = 0.0f;
-            dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
-            dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + j) * 32 + c] * inv_len : 0.0f;
-        }
-        // gate values (q 0-3: i, f, g, o; q 5: c of the step before -- each c_t is read once and carried) and dy of one
-        // step; [h | x] operand rows of one step.  Two of each, alternating: the step loop is unrolled by two.
-        struct QSet { float q[6][UPT], dy[DIRS][UPT]; };
-        struct XSet { f32x4 xh[MYNT > 0 ? MYNT : 1][4]; };
-        QSet qA, qB;
-        XSet xA, xB;
-        const float* dy0 = dy_in ? dy_in : tape_ld;          // last layer: any valid address, value unused
-        const bool has_dy = dy_in != nullptr;
-        const int64_t dy_tstep = has_dy ? (int64_t)H * 32 : 0, dy_pstep = has_dy ? dy_dir : 0;
-        unsigned off_q[5][UPT], off_dy[UPT], off_x[MYNT > 0 ? MYNT : 1];
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 16 * i;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) off_q[q][i] = (unsigned)((q * H + j) * 32 + c);
-            off_dy[i] = (unsigned)(j * 32 + c);
-        }
-#pragma unroll
-        for (int m = 0; m < MYNT; ++m) {
-            const int nt = T0 + m;
-            if (nt == 0) off_x[m] = (unsigned)(cl * 32 + 16 * hf);
+    for (int m = 0; m < MYNT; ++m) {
+        const int nt = T0 + m;
+        if (nt == 0) off_x[m] = (unsigned)(cl * 32 + 16 * hf);
+        else {
+            const int k = 32 * (nt - 1) + cl;
+            if (FIRST) off_x[m] = (unsigned)((k < y.Dp ? k : y.Dp - 1) * 32 + 16 * hf);   // clamped: columns >= Dp give dW columns nobody reads
             else {
-                const int k = 32 * (nt - 1) + cl;
-                if (FIRST) off_x[m] = (unsigned)((k < y.Dp ? k : y.Dp - 1) * 32 + 16 * hf);   // clamped: columns >= Dp give dW columns nobody reads
-                else {
-                    const int kc = k < DIRS * H ? k : DIRS * H - 1;
-                    const int dd = kc / H, kk = kc - dd * H;
-                    off_x[m] = (unsigned)((int64_t)dd * p.max_T * ts + kk * 32 + 16 * hf);
-                }
+                const int kc = k < DIRS * H ? k : DIRS * H - 1;
+                const int dd = kc / H, kk = kc - dd * H;
+                off_x[m] = (unsigned)((int64_t)dd * p.max_T * ts + kk * 32 + 16 * hf);
             }
         }
-        const float* x_base = FIRST ? xtile : tape + (int64_t)((l - 1) * DIRS) * p.max_T * ts + 5 * H * 32;
-        const int64_t x_step = FIRST ? (int64_t)y.Dp * 32 : ts;
-        struct FetchBase { const float *tq, *tqp, *dyb, *xb; int t; };
-        auto fetch_base = [&](int step) {                    // step < 0 (nothing left to fetch): step 0's addresses, values unused
+    }
+    const int64_t x_step = FIRST ? (int64_t)y.Dp * 32 : ts;
+    constexpr int NQ = UPT * 5, NDY = UPT * DIRS, NQL = NQ + NDY, NXH = MYNT * 4, NST = FIRST ? 0 : MTX * 2;
+
+    // One tile's addresses.  The operands of a tile's first two steps are fetched during the last two steps of the
+    // tile before it (the fetches that would otherwise run past the tile's end), and its per-curve values at that
+    // tile's start: a tile boundary then costs the fill of the step pipeline, not three dependent trips to HBM.
+    struct TileCtx { int tile, T; const float *tape_ld, *x_base, *dy0; };
+    const int NB = (p.n_tiles + G - 1) / G;
+    auto tile_of = [&](int band) {
+        if (band >= NB) return -1;
+        const int tl = band * G + ((band & 1) ? G - 1 - g : g);
+        return tl < p.n_tiles ? tl : -1;
+    };
+    auto make_ctx = [&](int tile, int T, int64_t x_off) {
+        TileCtx cx;
+        cx.tile = tile; cx.T = T;
+        const float* tape = p.tape + (int64_t)tile * p.tape_tile;
+        cx.tape_ld = tape + (int64_t)ld * p.max_T * ts;
+        cx.x_base = FIRST ? p.xp + x_off : tape + (int64_t)((l - 1) * DIRS) * p.max_T * ts + 5 * H * 32;
+        cx.dy0 = has_dy ? dy_in_base + ((int64_t)tile * DIRS + d) * p.max_T * H * 32 : cx.tape_ld;   // last layer: any valid address, value unused
+        return cx;
+    };
+    auto uniform64 = [](int64_t v) {
+        const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+        return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    };
+    int tile0 = tile_of(0);
+    TileCtx cur = make_ctx(0, 1, 0);
+    if (tile0 >= 0) cur = make_ctx(tile0, __builtin_amdgcn_readfirstlane(p.tile_T[tile0]), FIRST ? uniform64(p.tile_off[tile0]) : 0);
+    // values of the NEXT tile, fetched with vector loads (in-order vmcnt; a scalar load would be waited for at the next LDS wait)
+    int nT_v = 0, n_len = 0, n_order = 0;
+    int64_t n_xoff_v = 0;
+    float n_dhr[UPT], n_cc[UPT];
+    int T_n2 = 0;                              // T and x offset of the tile after the current one, as scalars
+    int64_t xoff_n2 = 0;
+    {
+        const int t1 = tile_of(1);
+        nT_v = t1 >= 0 ? p.tile_T[t1] : 0;
+        n_xoff_v = (FIRST && t1 >= 0) ? p.tile_off[t1] : 0;
+    }
+    // dy of the step before, stored during the next step's phase P -- across a tile boundary too: the last step's dy of a
+    // tile goes out in the first step of the next (a store at a tile's end would sit in front of the waits of its start)
+    float pend[MTX * 2];
+#pragma unroll
+    for (int i = 0; i < MTX * 2; ++i) pend[i] = 0.0f;
+    float* pend_slot = nullptr;
+    bool pref = false;                         // this tile's first operands and per-curve values are already in registers
+    for (int band = 0; tile0 >= 0 && band < NB; ++band) {
+        const int tile = cur.tile, T = cur.T;
+        if (tile_of(band) < 0) break;
+#ifdef SNN_PROBE_STREAM
+        const long long ph0 = clock64();
+#endif
+        // ---- the tile after this one
+        const int tile_n = tile_of(band + 1);
+        const int T_n = __builtin_amdgcn_readfirstlane(nT_v);
+        xoff_n2 = FIRST ? uniform64(n_xoff_v) : 0;
+        const bool has_next = tile_n >= 0 && T_n >= 1;
+        const TileCtx nxt_real = make_ctx(tile_n >= 0 ? tile_n : tile, T_n, xoff_n2);
+        const TileCtx nxt = has_next ? nxt_real : cur;   // for the fetches; no next tile: valid addresses, values unused
+        {
+            const int t2 = tile_of(band + 2);
+            nT_v = t2 >= 0 ? p.tile_T[t2] : 0;
+            n_xoff_v = (FIRST && t2 >= 0) ? p.tile_off[t2] : 0;
+        }
+        if (T < 1) {
+            cur = nxt_real; pref = false;
+            if (tile_n < 0) break;
+            continue;
+        }
+        int* origs_c = origs_lds + 32 * (band & 1);
+        int* origs_n = origs_lds + 32 * ((band & 1) ^ 1);
+        int len, order_c;
+        float dc[UPT], dhr[UPT], dfm[UPT], c_carry[UPT];
+        const float* dfeat = p.dfeat + (int64_t)tile * y.F * 32;
+        if (pref) {
+            len = n_len; order_c = n_order;
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) { dhr[i] = n_dhr[i]; c_carry[i] = n_cc[i]; }
+        } else {
+            len = p.len_sorted[tile * SNN_TILE + c];
+            order_c = p.order[tile * SNN_TILE + c];
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[((jg + 16 * i) * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
+                c_carry[i] = (cur.tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts + (4 * H + 16 * i) * 32)[off0];   // c of the first processed step
+            }
+        }
+        const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            dc[i] = 0.0f;
+            dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + jg + 16 * i) * 32 + c] * inv_len : 0.0f;
+        }
+        {   // the next tile's per-curve values (no next tile: this tile's, unused)
+            const float* dfeat_n = p.dfeat + (int64_t)nxt.tile * y.F * 32;
+            n_len = p.len_sorted[nxt.tile * SNN_TILE + c];
+            if (masked) n_order = p.order[nxt.tile * SNN_TILE + c];
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                n_dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat_n[((jg + 16 * i) * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
+                n_cc[i] = (nxt.tape_ld + (int64_t)(d == 0 ? nxt.T - 1 : 0) * ts + (4 * H + 16 * i) * 32)[off0];
+            }
+        }
+#ifdef SNN_PROBE_STREAM
+        const long long ph1 = clock64();
+#endif
+        __syncthreads();                       // previous tile done with LDS
+#ifdef SNN_PROBE_STREAM
+        const long long ph2 = clock64();
+#endif
+        if (!pref) {
+            if (tid < 32) origs_c[tid] = order_c;
+            __syncthreads();
+        }
+
+        struct FetchBase { const float *tq, *tqp, *dyb, *xb; const int* og; int t; };
+        auto fetch_base = [&](int step) {      // step < 0: the first steps of the next tile (no next tile: a valid address of this one, values unused)
             FetchBase fb;
-            if (step < 0) step = 0;
-            fb.t = d == 0 ? step : T - 1 - step;
+            const bool nx = step < 0;
+            const TileCtx& cx = nx ? nxt : cur;
+            if (nx) { step += cx.T; if (step < 0) step = 0; }
+            fb.t = d == 0 ? step : cx.T - 1 - step;
             const int tpc = step > 0 ? (d == 0 ? fb.t - 1 : fb.t + 1) : fb.t;      // clamped: step 0 has no predecessor
-            fb.tq = tape_ld + (int64_t)fb.t * ts;
-            fb.tqp = tape_ld + (int64_t)tpc * ts;
-            fb.dyb = dy0 + (int64_t)fb.t * dy_tstep;
-            fb.xb = x_base + (int64_t)fb.t * x_step;
+            fb.tq = cx.tape_ld + (int64_t)fb.t * ts;
+            fb.tqp = cx.tape_ld + (int64_t)tpc * ts;
+            fb.dyb = cx.dy0 + (int64_t)fb.t * dy_tstep;
+            fb.xb = cx.x_base + (int64_t)fb.t * x_step;
+            fb.og = nx ? origs_n : origs_c;
             return fb;
         };
-        constexpr int NQ = UPT * 5, NDY = UPT * DIRS, NQL = NQ + NDY, NXH = MYNT * 4, NST = FIRST ? 0 : MTX * 2;
-        float pend[MTX * 2];
-#pragma unroll
-        for (int i = 0; i < MTX * 2; ++i) pend[i] = 0.0f;
-        int pend_t = -1;
         auto piece_q = [&](int k, const FetchBase& fb, QSet& nv) {
             if (k < NQ) {
                 const int i = k / 5, q = k - 5 * i;
-                if (q < 4) nv.q[q][i] = fb.tq[off_q[q][i]];
-                else nv.q[5][i] = fb.tqp[off_q[4][i]];
+                if (q < 4) nv.q[q][i] = (fb.tq + (q * H + 16 * i) * 32)[off0];
+                else nv.q[5][i] = (fb.tqp + (4 * H + 16 * i) * 32)[off0];
             } else if (k < NQL) {
                 const int kk = k - NQ, i = kk / DIRS, pd = kk - DIRS * i;
-                nv.dy[pd][i] = (fb.dyb + pd * dy_pstep)[off_dy[i]];
+                nv.dy[pd][i] = (fb.dyb + pd * dy_pstep + 16 * i * 32)[off0];
             }
         };
         auto piece_x = [&](int k, const FetchBase& fb, XSet& nv) {
@@ -170,7 +247,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                     const int kcol = 32 * (nt - 1) + cl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int o = origs[16 * hf + 4 * q + e];
+                        const int o = fb.og[16 * hf + 4 * q + e];
                         if (o >= 0 && kcol < (FIRST ? y.D : DIRS * H))
                             v[e] = __fmul_rn(FIRST ? mask_in(p.mk, 0, p.n_curves, y.D, o, kcol)
                                                    : mask_mid(p.mk, 0, y.L, p.n_curves, DIRS * H, l - 1, fb.t, o, kcol), v[e]);
@@ -186,9 +263,6 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             }
         };
         auto dy_slot = [&](int tt) { return dy_out_base + (int64_t)d * dy_dir + ((int64_t)tile * DIRS * p.max_T + tt) * H * 32; };
-        float c_carry[UPT];
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) c_carry[i] = (tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts)[off_q[4][i]];   // c of the first processed step
         bool valid_prev = false;
         int t_prev = 0;
 
@@ -284,7 +358,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             mf(10);
             // dy of the step before (its stores go out during the next phase P)
             if (!FIRST) {
-                const int o = masked ? origs[c] : 0;
+                const int o = masked ? origs_c[c] : 0;
 #pragma unroll
                 for (int i = 0; i < MTX * 2; ++i) {
                     float s = ((r2[i][0] + r2[i][1]) + r2[i][2]) + r2[i][3];
@@ -294,7 +368,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                     }
                     pend[i] = with_red ? s : pend[i];
                 }
-                pend_t = with_red ? t_prev : pend_t;
+                pend_slot = with_red ? dy_slot(t_prev) : pend_slot;
             }
             mf(11);
 #pragma unroll
@@ -319,8 +393,9 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #ifdef SNN_PROBE_STREAM
             const long long pt1 = clock64();
 #endif
+            if (masked && tid < 32) origs_n[tid] = n_order;   // the next tile's curves, for the masks of its first [h | x] fetch (in phase Q, behind barrier Y)
             const FetchBase fq = fetch_base(step - 2), fx = fetch_base(step - 1);
-            float* st_base = FIRST ? nullptr : dy_slot(pend_t >= 0 ? pend_t : t);
+            float* st_base = FIRST ? nullptr : (pend_slot ? pend_slot : dy_slot(t));   // (the very first step: zeros into its own slot, overwritten one step later by the same thread)
             constexpr int NPP = NQL + NST;                                    // memory pieces of phase P
             const float* dgb = dGl + b * 4 * H * SP;
             float av[16];                                                     // phase Q's A operand (dG_t columns), fetched during phase P
@@ -378,7 +453,6 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             const long long pt3 = clock64();
 #endif
             // ---- phase Q
-            if (SNN_S3_PRIO == 2 && ROLE == 1) __builtin_amdgcn_s_setprio(1);
             if (ROLE == 0 && step == 0) {       // the tile's last step: h before it is the zero initial state (uniform branch)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -395,6 +469,8 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
+                // (the MFMAs evenly over the slices; issuing few of them before barrier X and the rest back to back after
+                //  it -- 9 + 0, 0 + 0, 18 + 0, 9 + 4 of role 0 + role 1 -- measured 2 to 6 % slower)
 #pragma unroll
                 for (int m = (k * NM) / 16; m < ((k + 1) * NM) / 16; ++m) {
                     const int kk = m / (MYNT > 0 ? MYNT : 1), mi = m - kk * (MYNT > 0 ? MYNT : 1);
@@ -405,41 +481,66 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                 __builtin_amdgcn_sched_barrier(0);
             };
             algebra(step - 1, step > 0, nq, true, b ^ 1, mf);
-            if (SNN_S3_PRIO == 2 && ROLE == 1) __builtin_amdgcn_s_setprio(0);
 #ifdef SNN_PROBE_STREAM
             probe[1] += pt2 - pt1; probe[2] += pt3 - pt2; probe[3] += clock64() - pt3; probe[4] += 1;
 #endif
         };
-        // ---- prologue: operands of the first two steps, gate gradients of the first
+        // ---- prologue: operands of the first two steps (unless the tile before fetched them), gate gradients of the first
         {
-            const FetchBase f0 = fetch_base(T - 1), f1 = fetch_base(T - 2);
+            if (!pref) {
+                const FetchBase f0 = fetch_base(T - 1);
 #pragma unroll
-            for (int k = 0; k < NQL; ++k) piece_q(k, f0, qA);
+                for (int k = 0; k < NQL; ++k) piece_q(k, f0, qA);
 #pragma unroll
-            for (int k = 0; k < NXH; ++k) piece_x(k, f0, xA);
+                for (int k = 0; k < NXH; ++k) piece_x(k, f0, xA);
+            }
+            if (!pref || T == 1) {             // (a one-step tile: what the tile before fetched as "second step" is not the next tile's first)
+                const FetchBase f1 = fetch_base(T - 2);
 #pragma unroll
-            for (int k = 0; k < NQL; ++k) piece_q(k, f1, qB);
+                for (int k = 0; k < NQL; ++k) piece_q(k, f1, qB);
+            }
             algebra(T - 1, true, qA, false, 0, [](int) {});
         }
+#ifdef SNN_PROBE_STREAM
+        const long long ph3 = clock64();
+        pst[10] += ph1 - ph0; pst[11] += ph2 - ph1; pst[0] += ph3 - ph2;
+#endif
         int step = T - 1;
         for (; step >= 1; step -= 2) {
             do_step(step, qA, qB, xA, xB, 0);
             do_step(step - 1, qB, qA, xB, xA, 1);
         }
         if (step == 0) do_step(0, qA, qB, xA, xB, 0);
-        if (!FIRST && pend_t >= 0) {           // the dy of the tile's last step
-            float* st_last = dy_slot(pend_t);
-#pragma unroll
-            for (int k = 0; k < NST; ++k) piece_s(k, st_last);
+#ifdef SNN_PROBE_STREAM
+        const long long ph4 = clock64();
+#endif
+        if (T & 1) {                           // the sets alternate per step: after an odd tile the next tile's first step sits in the B sets
+            const QSet tq = qA; qA = qB; qB = tq;    // (moving a register waits for its fetch: done before the stores below are
+            const XSet tx = xA; xA = xB; xB = tx;    //  issued, when the youngest outstanding fetch is half a step old)
         }
+#ifdef SNN_PROBE_STREAM
+        probe[0] += clock64() - ph4;
+#endif
+        cur = nxt_real;
+        pref = has_next;
+        if (tile_n < 0) break;
     }
 
+    if (!FIRST && pend_slot) {                 // the dy of the last step of the last tile
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int f = jg + 16 * k, dd = f / H, j = f - dd * H;
+            pend_slot[(int64_t)dd * p.max_T * H * 32 + j * 32 + c] = pend[k];
+        }
+    }
 #ifdef SNN_PROBE_STREAM
     if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)
         printf("probe3 l=%d role=%d steps=%lld  phase P %lld (products %lld)  barrier Y %lld  phase Q with barrier X %lld (slice starts 0, 2, .. 14: %lld %lld %lld %lld %lld %lld %lld %lld)  per step; loop total %lld per step\n",
                l, ROLE, probe[4], probe[1] / probe[4], pst[1] / probe[4], probe[2] / probe[4], probe[3] / probe[4],
                pst[2] / probe[4], pst[3] / probe[4], pst[4] / probe[4], pst[5] / probe[4], pst[6] / probe[4], pst[7] / probe[4], pst[8] / probe[4], pst[9] / probe[4],
                (clock64() - pk0) / probe[4]);
+    if (blockIdx.x == 0 && (threadIdx.x & 255) == 0)
+        printf("probe3t l=%d role=%d per tile (16 tiles): head loads %lld  barrier %lld  prologue %lld  tail %lld\n", l, ROLE, pst[10] / 16, pst[11] / 16, pst[0] / 16, probe[0] / 16);
 #endif
     // ---- this workgroup's partial sums -> its slab (canonical layout, only the (layer, direction) slices it owns)
     float* slab = p.slabs + (int64_t)blockIdx.x * y.P;
