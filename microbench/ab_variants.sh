@@ -1,7 +1,7 @@
 #!/bin/bash
-# bench_train.py phase times for the in-tree library and for variants/libsnn_<NAME>.so, all with SNN_STREAM3=1.
+# bench_train.py phase times for the in-tree library and for variants/libsnn_<NAME>.so.
 # usage: ab_variants.sh <batch> <name>...
-R=$GRAFT_REPO_ROOT; B=$1; shift; O=$R/gpurun_out/ab_variants; mkdir -p $O; export SNN_STREAM3=1
+R=$GRAFT_REPO_ROOT; B=$1; shift; O=$R/gpurun_out/ab_variants; mkdir -p $O
 for v in default "$@"; do
   if [ "$v" = default ]; then unset SNN_HIP_LIB; else export SNN_HIP_LIB=$R/variants/libsnn_$v.so; fi
   timeout -k 10 120 python3 -u $R/bench_train.py --batch $B --steps 20 --warmup 5 --cpu-steps 0 > $O/${v}_b$B.log 2>&1 || { echo "$v failed"; tail -5 $O/${v}_b$B.log; exit 1; }
