@@ -81,19 +81,49 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
     const bool has_dy = !last_layer;
     const int64_t dy_tstep = has_dy ? (int64_t)H * 32 : 0, dy_pstep = has_dy ? dy_dir : 0;
     // element (hidden unit jg + 16 i, curve c) of a [H][32] block: one per-lane offset, the rest goes into the (scalar) base
-    const unsigned off0 = (unsigned)(jg * 32 + c);
+    // Per-lane offsets are kept in BYTES in 32 bits and added to a wave-uniform base: the load then takes the form
+    // global_load v, v_off, s[base:base+1] with no vector arithmetic (an offset in floats has to be widened and
+    // shifted per load -- 2 - 3 vector instructions each, on a pipe the fp32 MFMAs share).
+    const unsigned off0 = (unsigned)(jg * 32 + c) * 4u;
+    // (The empty asm keeps the widening of the offset next to its use -- hoisted out of the loop it lands in another basic
+    //  block, where instruction selection no longer sees "uniform base + zero-extended 32-bit offset" -- and the base whole:
+    //  the compiler otherwise moves a constant part of it behind the vector add.)
+    typedef const __attribute__((address_space(1))) char* gcptr;     // (behind the asm the compiler no longer knows the pointer is global)
+    typedef __attribute__((address_space(1))) char* gptr;
+    auto ldf = [](const float* sb, unsigned boff) {
+#ifdef SNN_S3_PLAIN_ADDR
+        return sb[boff >> 2];
+#endif
+        asm volatile("" : "+s"(sb), "+v"(boff));
+        return *reinterpret_cast<const __attribute__((address_space(1))) float*>((gcptr)sb + boff);
+    };
+    auto ld4 = [](const float* sb, unsigned boff) {
+#ifdef SNN_S3_PLAIN_ADDR
+        return *reinterpret_cast<const f32x4*>(sb + (boff >> 2));
+#endif
+        asm volatile("" : "+s"(sb), "+v"(boff));
+        return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((gcptr)sb + boff);
+    };
+    auto stf = [](float* sb, unsigned boff, float v) {
+#ifdef SNN_S3_PLAIN_ADDR
+        sb[boff >> 2] = v;
+        return;
+#endif
+        asm volatile("" : "+s"(sb), "+v"(boff));
+        *reinterpret_cast<__attribute__((address_space(1))) float*>((gptr)sb + boff) = v;
+    };
     unsigned off_x[MYNT > 0 ? MYNT : 1];
 #pragma unroll
     for (int m = 0; m < MYNT; ++m) {
         const int nt = T0 + m;
-        if (nt == 0) off_x[m] = (unsigned)(cl * 32 + 16 * hf);
+        if (nt == 0) off_x[m] = (unsigned)(cl * 32 + 16 * hf) * 4u;
         else {
             const int k = 32 * (nt - 1) + cl;
-            if (FIRST) off_x[m] = (unsigned)((k < y.Dp ? k : y.Dp - 1) * 32 + 16 * hf);   // clamped: columns >= Dp give dW columns nobody reads
+            if (FIRST) off_x[m] = (unsigned)((k < y.Dp ? k : y.Dp - 1) * 32 + 16 * hf) * 4u;   // clamped: columns >= Dp give dW columns nobody reads
             else {
                 const int kc = k < DIRS * H ? k : DIRS * H - 1;
                 const int dd = kc / H, kk = kc - dd * H;
-                off_x[m] = (unsigned)((int64_t)dd * p.max_T * ts + kk * 32 + 16 * hf);
+                off_x[m] = (unsigned)((int64_t)dd * p.max_T * ts + kk * 32 + 16 * hf) * 4u;
             }
         }
     }
@@ -182,7 +212,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
                 dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[((jg + 16 * i) * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
-                c_carry[i] = (cur.tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts + (4 * H + 16 * i) * 32)[off0];   // c of the first processed step
+                c_carry[i] = ldf(cur.tape_ld + (int64_t)(d == 0 ? T - 1 : 0) * ts + (4 * H + 16 * i) * 32, off0);   // c of the first processed step
             }
         }
         const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
@@ -198,7 +228,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
                 n_dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat_n[((jg + 16 * i) * (y.L * DIRS) + ld) * 32 + c] : 0.0f;
-                n_cc[i] = (nxt.tape_ld + (int64_t)(d == 0 ? nxt.T - 1 : 0) * ts + (4 * H + 16 * i) * 32)[off0];
+                n_cc[i] = ldf(nxt.tape_ld + (int64_t)(d == 0 ? nxt.T - 1 : 0) * ts + (4 * H + 16 * i) * 32, off0);
             }
         }
 #ifdef SNN_PROBE_STREAM
@@ -226,23 +256,25 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             fb.dyb = cx.dy0 + (int64_t)fb.t * dy_tstep;
             fb.xb = cx.x_base + (int64_t)fb.t * x_step;
             fb.og = nx ? origs_n : origs_c;
+#ifdef SNN_ABL_S3_L2          // timing ablation: every fetch from the same few KB (cache hits), results wrong
+            fb.tq = fb.tqp = p.tape + (int64_t)ld * p.max_T * ts; fb.dyb = dy_in_base ? dy_in_base : p.tape; fb.xb = FIRST ? p.xp : p.tape;
+#endif
             return fb;
         };
         auto piece_q = [&](int k, const FetchBase& fb, QSet& nv) {
             if (k < NQ) {
                 const int i = k / 5, q = k - 5 * i;
-                if (q < 4) nv.q[q][i] = (fb.tq + (q * H + 16 * i) * 32)[off0];
-                else nv.q[5][i] = (fb.tqp + (4 * H + 16 * i) * 32)[off0];
+                if (q < 4) nv.q[q][i] = ldf(fb.tq + (q * H + 16 * i) * 32, off0);
+                else nv.q[5][i] = ldf(fb.tqp + (4 * H + 16 * i) * 32, off0);
             } else if (k < NQL) {
                 const int kk = k - NQ, i = kk / DIRS, pd = kk - DIRS * i;
-                nv.dy[pd][i] = (fb.dyb + pd * dy_pstep + 16 * i * 32)[off0];
+                nv.dy[pd][i] = ldf(fb.dyb + pd * dy_pstep + 16 * i * 32, off0);
             }
         };
         auto piece_x = [&](int k, const FetchBase& fb, XSet& nv) {
             if (k < NXH) {
                 const int m = k >> 2, q = k & 3, nt = T0 + m;
-                const float* src = (nt == 0 ? fb.tqp + 5 * H * 32 : fb.xb) + off_x[m];
-                f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);   // (h_prev of step 0: clamped address, zeroed before use)
+                f32x4 v = ld4((nt == 0 ? fb.tqp + 5 * H * 32 : fb.xb) + 4 * q, off_x[m]);   // (h_prev of step 0: clamped address, zeroed before use)
                 if (masked && nt > 0) {
                     const int kcol = 32 * (nt - 1) + cl;
 #pragma unroll
@@ -258,11 +290,15 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
         };
         auto piece_s = [&](int k, float* st_base) {         // one store of the dy the step before produced
             if (k < NST) {
-                const int f = jg + 16 * k, dd = f / H, j = f - dd * H;
-                st_base[(int64_t)dd * p.max_T * H * 32 + j * 32 + c] = pend[k];
+                // feature jg + 16 k of the layer below: direction k >> 1, hidden unit jg + 16 (k & 1)
+                stf(st_base + (int64_t)(k >> 1) * p.max_T * H * 32 + 16 * (k & 1) * 32, off0, pend[k]);
             }
         };
+#ifdef SNN_ABL_S3_NOSTORE      // timing ablation: all dy stores into one slot
+        auto dy_slot = [&](int tt) { return dy_out_base + (int64_t)d * dy_dir + 0 * tt; };
+#else
         auto dy_slot = [&](int tt) { return dy_out_base + (int64_t)d * dy_dir + ((int64_t)tile * DIRS * p.max_T + tt) * H * 32; };
+#endif
         bool valid_prev = false;
         int t_prev = 0;
 
@@ -278,11 +314,39 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
         };
         // The gate gradients of step `step` (live: it exists) into dG buffer wb; with_red: first the reduction of the
         // step processed before it (dh from red, its dy from red2).  Cut into 16 slices; mf(k) is called after slice k.
-        auto algebra = [&](int step, bool live, const QSet& cv, bool with_red, int wb, auto&& mf) {
+        // Everything of a step's gate gradients that does not depend on dh -- tanh(c), the derivative factors of the four
+        // gates, dy from above -- is computed ahead (during phase P, from gate values fetched a step earlier), so that
+        // between barrier Y and barrier X only  dh -> dc -> dG  remains: on this pipe a vector instruction waits for the
+        // MFMA in flight, and the waves of a workgroup all sit in that chain at the same time.
+        struct Fac { float A[UPT], Bv[UPT], Gi[UPT], Gf[UPT], Gg[UPT], fg[UPT], dyv[UPT]; };
+        Fac fac;
+        auto precompute = [&](int step, bool live, const QSet& cv) {
             const int t = d == 0 ? step : T - 1 - step;
             const int tp = d == 0 ? t - 1 : t + 1;
             const bool valid = live && t < len;
             const bool prev_live = step > 0 && tp < len;
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const float ig = cv.q[0][i], fg = cv.q[1][i], gg = cv.q[2][i], og = cv.q[3][i];
+                const float cp = prev_live ? cv.q[5][i] : 0.0f;
+                const float tc = snn_tanh(c_carry[i]);
+                c_carry[i] = cv.q[5][i];                                      // this step's q 5 is the next step's c
+                fac.A[i] = valid ? og * (1.0f - tc * tc) : 0.0f;             // (selects, not products: tape and dy beyond a curve's end are never written)
+                fac.Bv[i] = valid ? tc * og * (1.0f - og) : 0.0f;
+                fac.Gi[i] = valid ? gg * ig * (1.0f - ig) : 0.0f;
+                fac.Gf[i] = valid ? cp * fg * (1.0f - fg) : 0.0f;
+                fac.Gg[i] = valid ? ig * (1.0f - gg * gg) : 0.0f;
+                fac.fg[i] = fg;
+                float dyv = cv.dy[0][i];
+                if (DIRS == 2) dyv += cv.dy[DIRS - 1][i];
+                dyv = has_dy ? dyv : 0.0f;
+                if (last_layer && y.pool == SNN_POOL_MEAN) dyv += dfm[i];
+                fac.dyv[i] = valid ? dyv : 0.0f;
+            }
+        };
+        auto algebra = [&](int step, bool live, bool with_red, int wb, auto&& mf) {
+            const int t = d == 0 ? step : T - 1 - step;
+            const bool valid = live && t < len;
             float r[UPT][4], r2[MTX * 2][4];
 #pragma unroll
             for (int i = 0; i < UPT; ++i)
@@ -306,41 +370,28 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                 dhr[i] = take ? s : dhr[i];
             }
             mf(2);
-            float tc[UPT], dh[UPT];
+            float dh[UPT], dct[UPT], dao[UPT], dai[UPT], daf[UPT], dag[UPT];
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-                float dyv = cv.dy[0][i];
-                if (DIRS == 2) dyv += cv.dy[DIRS - 1][i];
-                dh[i] = dhr[i] + (has_dy ? dyv : 0.0f);
-                if (last_layer && y.pool == SNN_POOL_MEAN) dh[i] += dfm[i];
+                dh[i] = dhr[i] + fac.dyv[i];
+                dct[i] = dc[i] + dh[i] * fac.A[i];
             }
             mf(3);
 #pragma unroll
-            for (int i = 0; i < UPT; ++i) tc[i] = snn_tanh(c_carry[i]);
+            for (int i = 0; i < UPT; ++i) {
+                dao[i] = dh[i] * fac.Bv[i];
+                dai[i] = dct[i] * fac.Gi[i];
+            }
             mf(4);
-            float dct[UPT], dao[UPT];
 #pragma unroll
             for (int i = 0; i < UPT; ++i) {
-                const float og = cv.q[3][i];
-                dct[i] = dc[i] + dh[i] * og * (1.0f - tc[i] * tc[i]);
-                dao[i] = valid ? dh[i] * tc[i] * og * (1.0f - og) : 0.0f;
+                daf[i] = dct[i] * fac.Gf[i];
+                dag[i] = dct[i] * fac.Gg[i];
             }
             mf(5);
-            float dai[UPT], daf[UPT], dag[UPT];
 #pragma unroll
-            for (int i = 0; i < UPT; ++i) {
-                const float ig = cv.q[0][i], gg = cv.q[2][i];
-                dai[i] = valid ? dct[i] * gg * ig * (1.0f - ig) : 0.0f;
-                dag[i] = valid ? dct[i] * ig * (1.0f - gg * gg) : 0.0f;
-            }
+            for (int i = 0; i < UPT; ++i) dc[i] = valid ? dct[i] * fac.fg[i] : dc[i];
             mf(6);
-#pragma unroll
-            for (int i = 0; i < UPT; ++i) {
-                const float fg = cv.q[1][i];
-                const float cp = prev_live ? cv.q[5][i] : 0.0f;
-                daf[i] = valid ? dct[i] * cp * fg * (1.0f - fg) : 0.0f;
-                dc[i] = valid ? dct[i] * fg : dc[i];
-            }
             mf(7);
             float* dg = dGl + wb * 4 * H * SP;
 #pragma unroll
@@ -377,8 +428,6 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #pragma unroll
             for (int i = 0; i < UPT; ++i) { db[2 * UPT + i] += dag[i]; db[3 * UPT + i] += dao[i]; }
             mf(13);
-#pragma unroll
-            for (int i = 0; i < UPT; ++i) c_carry[i] = cv.q[5][i];           // this step's q 5 is the next step's c
             mf(14);
             mf(15);
             valid_prev = valid;
@@ -394,6 +443,8 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
             const long long pt1 = clock64();
 #endif
             if (masked && tid < 32) origs_n[tid] = n_order;   // the next tile's curves, for the masks of its first [h | x] fetch (in phase Q, behind barrier Y)
+            precompute(step - 1, step > 0, nq);
+            __builtin_amdgcn_sched_barrier(0);
             const FetchBase fq = fetch_base(step - 2), fx = fetch_base(step - 1);
             float* st_base = FIRST ? nullptr : (pend_slot ? pend_slot : dy_slot(t));   // (the very first step: zeros into its own slot, overwritten one step later by the same thread)
             constexpr int NPP = NQL + NST;                                    // memory pieces of phase P
@@ -471,8 +522,13 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #endif
                 // (the MFMAs evenly over the slices; issuing few of them before barrier X and the rest back to back after
                 //  it -- 9 + 0, 0 + 0, 18 + 0, 9 + 4 of role 0 + role 1 -- measured 2 to 6 % slower)
+#ifdef SNN_S3_POSTX      // measurement build: all of the phase's MFMAs after barrier X (slices 9 .. 15)
+                const int m0 = k <= 8 ? 0 : ((k - 9) * NM) / 7, m1 = k <= 8 ? 0 : ((k - 8) * NM) / 7;
+#else
+                const int m0 = (k * NM) / 16, m1 = ((k + 1) * NM) / 16;
+#endif
 #pragma unroll
-                for (int m = (k * NM) / 16; m < ((k + 1) * NM) / 16; ++m) {
+                for (int m = m0; m < m1; ++m) {
                     const int kk = m / (MYNT > 0 ? MYNT : 1), mi = m - kk * (MYNT > 0 ? MYNT : 1);
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], cx.xh[mi][kk >> 2][kk & 3], acc[mi], 0, 0, 0);
                 }
@@ -480,7 +536,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                 for (int q = (k * NXH) / 16; q < ((k + 1) * NXH) / 16; ++q) piece_x(q, fx, nx);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            algebra(step - 1, step > 0, nq, true, b ^ 1, mf);
+            algebra(step - 1, step > 0, true, b ^ 1, mf);
 #ifdef SNN_PROBE_STREAM
             probe[1] += pt2 - pt1; probe[2] += pt3 - pt2; probe[3] += clock64() - pt3; probe[4] += 1;
 #endif
@@ -499,7 +555,8 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
 #pragma unroll
                 for (int k = 0; k < NQL; ++k) piece_q(k, f1, qB);
             }
-            algebra(T - 1, true, qA, false, 0, [](int) {});
+            precompute(T - 1, true, qA);
+            algebra(T - 1, true, false, 0, [](int) {});
         }
 #ifdef SNN_PROBE_STREAM
         const long long ph3 = clock64();
@@ -529,8 +586,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
     if (!FIRST && pend_slot) {                 // the dy of the last step of the last tile
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
-            const int f = jg + 16 * k, dd = f / H, j = f - dd * H;
-            pend_slot[(int64_t)dd * p.max_T * H * 32 + j * 32 + c] = pend[k];
+            stf(pend_slot + (int64_t)(k >> 1) * p.max_T * H * 32 + 16 * (k & 1) * 32, off0, pend[k]);
         }
     }
 #ifdef SNN_PROBE_STREAM
