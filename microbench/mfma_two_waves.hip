@@ -2,7 +2,7 @@
 // threads per CU (two waves per SIMD, as in bwd_stream3_kernel).  Per loop iteration a wave issues M MFMAs and V
 // DEPENDENT v_fma_f32; modes: 0 both waves run the same program; 1 waves 0-3 issue only the MFMAs, waves 4-7 only the
 // vector chain.  Prints cycles per iteration for the older and the younger wave of SIMD 0.
-//   hipcc -O3 --offload-arch=gfx950 microbench/pipe/mfma_valu_overlap.hip -o microbench/pipe/mfma_valu_overlap
+//   hipcc -O3 --offload-arch=gfx950 microbench/mfma_two_waves.hip -o microbench/mfma_two_waves
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
