@@ -1,19 +1,23 @@
-// snn_bwd_stream3.h -- streamed LSTM backward for H = 32, pipelined over consecutive steps (included by snn_train_big.hip).
+// snn_bwd_stream3.h -- streamed LSTM backward for H = 32, pipelined over consecutive steps and consecutive tiles
+// (included by snn_train_big.hip, which describes the formulation: who owns what, where dG, dW and db live).
 //
-// bwd_stream_kernel (snn_train_big.hip) runs a step as  algebra | barrier | products | barrier | reduction : measured
-// with clock64 probes, ~2 000 of its 9 400 cycles per step (layer 1) are the algebra / reduction phases and their
-// barriers -- LDS round trips and a dependent chain, with the matrix pipe idle.  Of the 48 / 96 MFMAs a SIMD issues per
-// step only W_hh^T dG_t (16) is on the recurrence.  This variant keeps the two roles and the register-resident dW
-// accumulators and re-orders a step so that the chain's vector work runs INSIDE the products that are off the chain:
-//   barrier X   dG_t complete (buffer b)
+// Its predecessor (microbench/experiments/snn_bwd_stream1.h) ran a step as  algebra | barrier | products | barrier |
+// reduction : measured with clock64 probes, ~2 000 of its 9 400 cycles per step (layer 1) were the algebra / reduction
+// phases and their barriers -- LDS round trips and a dependent chain, with the matrix pipe idle -- and a tile boundary
+// cost ~20 000 cycles (three dependent trips to HBM).  Of the 48 / 96 MFMAs a SIMD issues per step only W_hh^T dG_t (16)
+// is on the recurrence.  This kernel keeps the two roles and the register-resident dW accumulators and orders a step as
+//   barrier X   dG_t complete (buffer b); sits INSIDE phase Q of the step before, followed by the fetch of the
+//               dG operand of phase P
 //   phase P     role 0: dh partials = W_hh^T dG_t (16 MFMAs) -> red;  role 1: dy partials = W_ih^T dG_t -> red2;
-//               between the MFMAs: loads of the gate values of step t-2, stores of dy_{t+1}
+//               before the MFMAs: everything of step t-1's gate gradients that does not depend on dh (precompute);
+//               between the MFMAs: loads of the gate values of step t-2, stores of dy_{t+1}, the dG operand of phase Q
 //   barrier Y   red, red2 complete
-//   phase Q     dW += dG_t [h | x]^T (both roles), and dealt out BETWEEN those MFMAs (sched_barrier-pinned stages, as
-//               lstm_fwd_pair_kernel does it): the reduction of red -> dh_{t-1}, the gate gradients of step t-1 into dG
-//               buffer b^1, the reduction of red2 -> dy_t, and the loads of [h | x] of step t-1.
-// fp32 MFMA and the vector ALU are one pipe, so the vector instructions still cost their issue slots; what disappears
-// is every wait between them (LDS latency, transcendental latency, one barrier) -- they now pass under MFMAs.
+//   phase Q     dW += dG_t [h | x]^T (both roles), and dealt out BETWEEN those MFMAs in 16 slices pinned with
+//               sched_barrier: the reduction of red -> dh_{t-1}, the gate gradients of step t-1 into dG buffer b^1,
+//               barrier X, the reduction of red2 -> dy_t, and the loads of [h | x] of step t-1.
+// Across a tile's end the same fetches address the first two steps of the stripe's next tile.
+// What this does not buy (microbench/mfma_two_waves.hip): a wave does not overlap its own vector instructions with its
+// own fp32 MFMA, so phase Q still costs its MFMAs plus its chain; DESIGN.md lists what was tried against that.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -521,7 +525,7 @@ __device__ __forceinline__ void bwd_stream3_role(const Bwd2Params& p, int l, int
                 }
 #endif
                 // (the MFMAs evenly over the slices; issuing few of them before barrier X and the rest back to back after
-                //  it -- 9 + 0, 0 + 0, 18 + 0, 9 + 4 of role 0 + role 1 -- measured 2 to 6 % slower)
+                //  it -- 0 + 0, 18 + 0, 9 + 4 of role 0 + role 1 -- measured 2 to 4 % slower)
 #ifdef SNN_S3_POSTX      // measurement build: all of the phase's MFMAs after barrier X (slices 9 .. 15)
                 const int m0 = k <= 8 ? 0 : ((k - 9) * NM) / 7, m1 = k <= 8 ? 0 : ((k - 8) * NM) / 7;
 #else
