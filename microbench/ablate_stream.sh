@@ -1,5 +1,5 @@
 #!/bin/bash
-# Timing ablations of bwd_stream_kernel (variants/libsnn_<NAME>.so built with -DSNN_ABL_STREAM_* / -DSNN_STREAM_OCC=2):
+# Timing ablations of the streamed backward (variants/libsnn_<NAME>.so built with microbench/build_variant.sh and -DSNN_ABL_S3_L2 / -DSNN_ABL_S3_NOSTORE / -DSNN_S3_POSTX / -DSNN_STREAM_OCC=2):
 # rocprofv3 kernel-trace of bench_train.py at one batch size per variant; prints the stream kernels' average times.
 R=$GRAFT_REPO_ROOT; B=${1:-65536}; O=$R/gpurun_out/ablate_stream/b$B; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for v in default "$@"; do
