@@ -439,17 +439,19 @@ def test_pack_x_refuses_a_buffer_smaller_than_the_plan():
 @pytest.mark.parametrize("D,dirs,pool,C,masked", [(24, 2, "mean", 2, False), (48, 2, "standard", 5, True),
                                                   (78, 1, "mean", 3, False), (26, 1, "standard", 2, True)])
 def test_streamed_backward_equals_split_backward(D, dirs, pool, C, masked):
-    """H = 32 runs the streamed backward (bwd_stream_kernel: one pass per (layer, direction), dG in LDS, dW in
-    registers over a stripe of tiles); the round-1 split path (bwd_rec / bwd_dx / bwd_dw through HBM) stays selectable
-    with SNN_BWD_PATH=split.  Same tape, same dlogits: the two give the same gradient up to summation order, for more
-    tiles than workgroups (stripes of several tiles, serpentine) and for a handful of tiles."""
+    """H = 32 runs the streamed backward (bwd_stream3_kernel: one pass per (layer, direction), dG in LDS, dW in
+    registers over a stripe of tiles, steps and tiles pipelined); the round-1 split path (bwd_rec / bwd_dx / bwd_dw
+    through HBM) stays selectable with SNN_BWD_PATH=split.  Same tape, same dlogits: the two give the same gradient up to
+    summation order, for more tiles than workgroups (stripes of 2 - 3 tiles, serpentine), for stripes of 5 tiles of at
+    most 7 steps (odd and even tile lengths, one-step tiles at the short end: the cross-tile fetches) and for a handful
+    of tiles."""
     import os
     from supernnova_amd import engine as E
     from util import make_curves
     cfg = E.Config(D, 32, 2, dirs == 2, C, pool)
     w = np.random.default_rng(4).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
     wk = E.prepare_weights(cfg, _t(w))
-    for n, T in ((9000, 30), (70, 12)):
+    for n, T in ((9000, 30), (20000, 7), (70, 12)):
         x, lengths = make_curves(33, n, T, D, min_len=1)
         plan = E.Plan(cfg, lengths, DEV)
         xp = E.pack_x(cfg, plan, _t(x))
