@@ -166,8 +166,10 @@ int64_t snn_x_step_floats(const snn_cfg *cfg); /* 4-byte words of ONE time step 
  *                           (tile i occupies tile_T[i] * Dp * 32 floats, Dp = D padded to the next supported width:
  *                           24, 26, 48, 76 or 78); tile_off[n_tiles] / (Dp*32) is the total number of tile-steps,
  *                           and the packed buffer holds that many times snn_x_step_floats(cfg) words
- * n_tiles = ceil(n_curves/32).  Lengths must be >= 1.
+ * n_tiles = ceil(n_curves/32).  Lengths must lie in [1, SNN_MAX_STEPS] (anything else is refused with SNN_ERR_ARG;
+ * the bound keeps the sort's bucket table small whatever the caller passes).
  */
+#define SNN_MAX_STEPS (1 << 22)
 int snn_plan_build(const snn_cfg *cfg, const int32_t *lengths_host, int32_t n_curves,
                    int32_t *order, int32_t *len_sorted, int32_t *tile_T, int64_t *tile_off);
 
@@ -325,7 +327,16 @@ int snn_lstm_forward_train(const snn_cfg *cfg, const float *xp, const int32_t *l
                            const snn_masks *masks, float *out_logits, float *tape, int64_t tape_floats,
                            void *workspace, int64_t workspace_bytes, void *stream);
 
+/*
+ * Workspace of snn_lstm_backward.  The backward has three implementations with results equal to the gradient bar
+ * (streamed / split / fused; they differ in summation order, ~1e-5 relative), chosen per call from (cfg, n_tiles) and
+ * the environment variable SNN_BWD_PATH=stream|split|fused (A/B measurements, read at every call): the size returned
+ * here is that of the path THIS call would pick, so query it again whenever n_tiles or the variable may have changed
+ * instead of caching it by (cfg, max_T) -- snn_lstm_backward refuses a workspace that is too small for its path with
+ * SNN_ERR_WORKSPACE.  snn_last_backward_path() names the path the calling thread's last snn_lstm_backward took.
+ */
 int64_t snn_lstm_backward_workspace_bytes(const snn_cfg *cfg, int32_t n_tiles, int32_t max_T);
+const char *snn_last_backward_path(void);
 
 /*
  * BPTT: gradients of a scalar loss w.r.t. the weight set used by snn_lstm_forward_train, given

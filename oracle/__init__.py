@@ -32,10 +32,18 @@ def build():
 
 
 _libs = {}
+_fp32_name = "libsnn_oracle.so"
+
+
+def use_library(name):
+    """Route the fp32 entry points through another build of the same source (tests/test_host_sanitizers.py:
+    libsnn_oracle_asan.so, built by `make -C oracle asan`)."""
+    global _fp32_name
+    _fp32_name = name
 
 
 def _lib(f64=False):
-    name = "libsnn_oracle_f64.so" if f64 else "libsnn_oracle.so"
+    name = "libsnn_oracle_f64.so" if f64 else _fp32_name
     if name not in _libs:
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):

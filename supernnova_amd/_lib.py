@@ -84,6 +84,7 @@ SIGNATURES = {
                                               ctypes.c_int32, _P, ctypes.POINTER(SnnMasks), _P, _P, ctypes.c_int64,
                                               _P, ctypes.c_int64, _P]),
     "snn_lstm_backward_workspace_bytes": (ctypes.c_int64, [_CFG, ctypes.c_int32, ctypes.c_int32]),
+    "snn_last_backward_path": (ctypes.c_char_p, []),
     "snn_lstm_backward": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          _P, ctypes.POINTER(SnnMasks), _P, ctypes.c_int64, _P, _P, ctypes.c_int32,
                                          _P, ctypes.c_int64, _P]),

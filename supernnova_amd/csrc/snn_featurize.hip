@@ -92,7 +92,9 @@ extern "C" int snn_featurize_fill(int64_t n, int64_t n_rows, int32_t F, const in
         return SNN_ERR_ARG;
     }
     for (int64_t j = 0; j < n; ++j) {                 // rows of one light curve are contiguous: no two threads share a row
-        const int64_t i = order[j], r = row_of[j], k = filt[i];
+        const int64_t i = order[j], r = row_of[j];
+        if (i < 0 || i >= n) { snn_set_error("snn_featurize_fill: order[%lld] = %lld outside [0, n)", (long long)j, (long long)i); return SNN_ERR_ARG; }
+        const int64_t k = filt[i];
         if (r < 0 || r >= n_rows || k >= F) { snn_set_error("snn_featurize_fill: row or filter index out of range"); return SNN_ERR_ARG; }
         row_mjd[r] = row_mjd_of[j];
         if (k < 0) continue;

@@ -259,58 +259,9 @@ __global__ void __launch_bounds__(64) head_combine_kernel(const FwdParams p, int
 // ============================================================================
 // host side
 // ============================================================================
-static thread_local char g_err[512] = "";
-void snn_set_error(const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-extern "C" const char* snn_last_error(void) { return g_err; }
 // name and launch geometry of the forward kernel this thread dispatched last (reports and benchmarks name what ran)
 static thread_local char g_last_kernel[160] = "";
 extern "C" const char* snn_last_forward_kernel(void) { return g_last_kernel; }
-extern "C" int snn_version(void) { return 100; }
-
-int snn_make_layout(const snn_cfg* cfg, SnnLayout* y)
-{
-    if (!cfg) { snn_set_error("cfg is NULL"); return SNN_ERR_ARG; }
-    if (snn_layout_init(y, cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->bidirectional,
-                        cfg->nb_classes, cfg->pool, cfg->precision, cfg->cell) != 0) {
-        snn_set_error("invalid cfg: D=%d H=%d L=%d C=%d pool=%d precision=%d cell=%d (need H %% 8 == 0, 1 <= L <= %d; GRU / RNN "
-                      "cells in SNN_PREC_F32 only)", cfg->input_size, cfg->hidden_size, cfg->num_layers, cfg->nb_classes,
-                      cfg->pool, cfg->precision, cfg->cell, SNN_MAX_LAYERS);
-        return SNN_ERR_ARG;
-    }
-    return SNN_OK;
-}
-
-extern "C" int64_t snn_param_count(const snn_cfg* cfg)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    return rc ? rc : y.P;
-}
-extern "C" int64_t snn_kparam_count(const snn_cfg* cfg)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    return rc ? rc : y.PK;
-}
-extern "C" int64_t snn_x_step_floats(const snn_cfg* cfg)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    if (rc) return rc;
-    return y.prec != 0 ? (int64_t)y.XB[0] * y.NPC * 64 * 4 : (int64_t)y.Dp * SNN_TILE;
-}
-extern "C" int32_t snn_feat(const snn_cfg* cfg)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    return rc ? rc : y.F;
-}
 
 // ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
@@ -355,42 +306,6 @@ extern "C" int snn_supported(const snn_cfg* cfg)
     if (y.prec == 1) return snn_b3_kernel(y.H, y.XB[0], y.dirs) != nullptr;
     if (y.prec == 2) return snn_h2_kernel(y.H, y.XB[0], y.dirs, false) != nullptr;
     return find_fwd(y) != nullptr;
-}
-
-extern "C" int snn_plan_build(const snn_cfg* cfg, const int32_t* lengths, int32_t n, int32_t* order,
-                              int32_t* len_sorted, int32_t* tile_T, int64_t* tile_off)
-{
-    SnnLayout y;
-    int rc = snn_make_layout(cfg, &y);
-    if (rc) return rc;
-    if (!lengths || !order || !len_sorted || !tile_T || !tile_off || n < 1) {
-        snn_set_error("snn_plan_build: null pointer or n_curves < 1");
-        return SNN_ERR_ARG;
-    }
-    // counting sort by length, descending, stable
-    int32_t maxlen = 0;
-    for (int32_t i = 0; i < n; ++i) {
-        if (lengths[i] < 1) { snn_set_error("snn_plan_build: lengths[%d] = %d < 1", i, lengths[i]); return SNN_ERR_ARG; }
-        maxlen = std::max(maxlen, lengths[i]);
-    }
-    std::vector<int64_t> start((size_t)maxlen + 2, 0);
-    for (int32_t i = 0; i < n; ++i) start[(size_t)(maxlen - lengths[i]) + 1]++;
-    for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
-    const int32_t n_tiles = (n + SNN_TILE - 1) / SNN_TILE;
-    for (int64_t i = n; i < (int64_t)n_tiles * SNN_TILE; ++i) { order[i] = -1; len_sorted[i] = 0; }
-    for (int32_t i = 0; i < n; ++i) {
-        const int64_t pos = start[(size_t)(maxlen - lengths[i])]++;
-        order[pos] = i;
-        len_sorted[pos] = lengths[i];
-    }
-    int64_t off = 0;
-    for (int32_t t = 0; t < n_tiles; ++t) {
-        tile_T[t] = len_sorted[(int64_t)t * SNN_TILE];
-        tile_off[t] = off;
-        off += (int64_t)tile_T[t] * y.Dp * SNN_TILE;
-    }
-    tile_off[n_tiles] = off;
-    return SNN_OK;
 }
 
 #define HIP_CHECK(expr)                                                             \
@@ -804,6 +719,8 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     if (train && e->fn_train_layer && !no_layerwise && 256 + part_bytes <= workspace_bytes) {
         float* head_part = (float*)((char*)workspace + 256);
         HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_train_layer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "lstm_fwd_train_layer_kernel<%d,%d,%d> x %d layers grid=%d block=%d lds=%zu",
+                 y.H, y.KKI[0], y.dirs, y.L, n_tiles * y.dirs, g.threads, g.lds);
         for (int l = 0; l < y.L; ++l)
             hipLaunchKernelGGL(e->fn_train_layer, dim3(n_tiles * y.dirs), dim3(g.threads), g.lds, st, p, l, head_part);
         hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, y.H, y.dirs, y.k_head_b, head_part);

@@ -38,28 +38,35 @@ extern "C" int snn_h5_vlen_gather(const void* file_v, int64_t file_size, const v
         const int64_t len = rd32(d);
         const uint64_t addr = rd64(d + 4);
         const uint32_t idx = rd32(d + 12);
-        if (len == 0) continue;
+        // an empty element, or one whose heap address is 0 / "undefined" (all ones), holds nothing -- as h5reader._heap_object
+        if (len == 0 || addr == 0 || addr == ~(uint64_t)0) continue;
         const int64_t bytes = len * elem_size;
-        if (at + bytes > out_bytes) { snn_set_error("snn_h5_vlen_gather: output buffer too small"); return SNN_ERR_ARG; }
+        if (bytes > out_bytes - at) { snn_set_error("snn_h5_vlen_gather: output buffer too small"); return SNN_ERR_ARG; }
         auto it = cols.find(addr);
         if (it == cols.end()) {
-            if (addr + 16 > (uint64_t)file_size || memcmp(file + addr, "GCOL", 4) != 0) {
+            // every bound is tested by subtraction from a quantity already known to be in range: the fields come from the
+            // file and a sum such as addr + 16 wraps for addresses near 2^64
+            const uint64_t fsz = (uint64_t)file_size;
+            if (addr > fsz - 16 || memcmp(file + addr, "GCOL", 4) != 0) {
                 snn_set_error("snn_h5_vlen_gather: element %lld points to %llu, which is not a global heap collection",
                               (long long)i, (unsigned long long)addr);
                 return SNN_ERR_ARG;
             }
             const uint64_t csize = rd64(file + addr + 8);
-            if (addr + csize > (uint64_t)file_size) { snn_set_error("snn_h5_vlen_gather: collection runs past the end of the file"); return SNN_ERR_ARG; }
+            if (csize < 16 || csize > fsz - addr) { snn_set_error("snn_h5_vlen_gather: collection runs past the end of the file"); return SNN_ERR_ARG; }
             Collection c;
+            const uint64_t end = addr + csize;      // <= file_size: no wrap
             uint64_t p = addr + 16;
-            while (p + 16 <= addr + csize) {
+            while (end - p >= 16) {                 // p <= end throughout
                 const uint16_t oi = rd16(file + p);
                 const uint64_t osz = rd64(file + p + 8);
-                if (oi == 0) break;
-                if (p + 16 + osz > addr + csize) { snn_set_error("snn_h5_vlen_gather: heap object runs past its collection"); return SNN_ERR_ARG; }
+                if (oi == 0) break;                 // free space: by the format the last object of a collection
+                if (osz > end - p - 16) { snn_set_error("snn_h5_vlen_gather: heap object runs past its collection"); return SNN_ERR_ARG; }
                 if (c.by_index.size() <= oi) c.by_index.resize(oi + 1, HeapObj{-1, 0});
                 c.by_index[oi] = HeapObj{(int64_t)(p + 16), (int64_t)osz};
-                p += 16 + ((osz + 7) & ~(uint64_t)7);
+                const uint64_t adv = 16 + ((osz + 7) & ~(uint64_t)7);     // osz <= end - p - 16 < 2^63: no wrap
+                if (adv > end - p) break;           // padding of the last object may run to the collection's end
+                p += adv;
             }
             it = cols.emplace(addr, std::move(c)).first;
         }

@@ -85,6 +85,10 @@ int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* le
 
 static const int BWD_MAX_GRID = 256;
 
+// which of the three backward paths the calling thread's last snn_lstm_backward took (reports, tests)
+static thread_local const char* g_last_bwd_path = "";
+extern "C" const char* snn_last_backward_path(void) { return g_last_bwd_path; }
+
 static size_t bwd_lds_bytes(const SnnLayout& y)
 {
     const int xrows = std::max(y.dirs * y.H, 2 * y.KKI[0]), krows = y.H + xrows, mt = (krows + 31) / 32;
@@ -134,6 +138,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
         MaskP mk;
         rc = snn_masks_to_device(masks, max_T, &mk);
         if (rc) return rc;
+        g_last_bwd_path = "stream";
         return snn_lstm_backward_stream(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, mk, tape,
                                         tape_tile, dlogits, dflat, accumulate, workspace, workspace_bytes, stream);
     }
@@ -141,6 +146,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
         MaskP mk;
         rc = snn_masks_to_device(masks, max_T, &mk);
         if (rc) return rc;
+        g_last_bwd_path = "split";
         return snn_lstm_backward_big(y, xp, len_sorted, order, tile_T, tile_off, n_curves, n_tiles, max_T, wk, mk, tape,
                                      tape_tile, dlogits, dflat, accumulate, workspace, workspace_bytes, stream);
     }
@@ -150,6 +156,7 @@ extern "C" int snn_lstm_backward(const snn_cfg* cfg, const float* xp, const int3
         snn_set_error("snn_lstm_backward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)need);
         return SNN_ERR_WORKSPACE;
     }
+    g_last_bwd_path = "fused";
     const size_t lds = bwd_lds_bytes(y);
     if (lds > 160 * 1024) { snn_set_error("snn_lstm_backward: LDS request %zu exceeds 160 KiB", lds); return SNN_ERR_UNSUPPORTED; }
     BwdParams p;

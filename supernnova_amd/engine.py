@@ -301,14 +301,26 @@ _workspaces = {}
 
 def release_workspaces(device=None):
     """Drop the cached forward / backward workspaces (of `device`, or of every device)."""
+    if device is not None:
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:      # "cuda" means the current device; keys carry the index
+            device = torch.device("cuda", torch.cuda.current_device())
     for cache in (_workspaces, _bwd_workspaces):
-        for key in [k for k in cache if device is None or k[0] == torch.device(device)]:
+        for key in [k for k in cache if device is None or k[0] == device]:
             del cache[key]
+
+
+def _dev_key(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
 
 
 def _workspace(cfg, max_T, device):
     need = L.check(L.load().snn_lstm_forward_workspace_bytes(ctypes.byref(cfg.c), max_T),
                    "snn_lstm_forward_workspace_bytes")
+    device = _dev_key(device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
@@ -429,7 +441,7 @@ def lstm_backward(cfg, plan, xp, wk, tape, dlogits, masks=None, out=None, accumu
         raise L.SnnError(f"dlogits shape {tuple(dlogits.shape)} != ({plan.n_curves},{cfg.nb_classes})")
     need = L.check(L.load().snn_lstm_backward_workspace_bytes(ctypes.byref(cfg.c), plan.n_tiles, plan.max_T),
                    "snn_lstm_backward_workspace_bytes")
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (_dev_key(dev), torch.cuda.current_stream(dev).cuda_stream)
     ws = _bwd_workspaces.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -27,6 +27,32 @@ import numpy as np
 UNDEF = 0xFFFFFFFFFFFFFFFF
 
 
+class CorruptFile(ValueError):
+    """The file's own fields contradict each other or point outside the file (truncated or damaged database.h5)."""
+
+
+def _guard(fn):
+    """A damaged file shows up in the parser as struct.error / IndexError / OverflowError / RecursionError / ... from
+    wherever a field was followed; the public entry points turn all of them into CorruptFile (a ValueError), so callers
+    handle ONE exception type.  KeyError (a name that does not exist), NotImplementedError (a valid feature outside the
+    covered subset) and the native gather's SnnError pass through."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        except (KeyError, NotImplementedError, CorruptFile):
+            raise
+        except (struct.error, IndexError, OverflowError, RecursionError, MemoryError, UnicodeDecodeError, TypeError,
+                ValueError, ZeroDivisionError) as e:
+            raise CorruptFile(f"damaged or truncated HDF5 file: {type(e).__name__}: {e}") from e
+    return wrapped
+
+
+_MAX_BLOCKS = 4096          # object-header continuation blocks followed per object (a cycle would never end)
+
+
 class _Type:
     """Parsed datatype message."""
 
@@ -79,8 +105,11 @@ class _Object:
         ver, _, nmsg, _, hsize = struct.unpack_from("<BBHII", buf, addr)
         if ver != 1:
             raise ValueError(f"object header at {addr}: version {ver}")
-        blocks = [(addr + 16, hsize)]
+        blocks, seen = [(addr + 16, hsize)], 0
         while blocks and len(self.msgs) < nmsg:
+            seen += 1
+            if seen > _MAX_BLOCKS:
+                raise CorruptFile(f"object header at {addr}: continuation blocks do not end")
             p, n = blocks.pop(0)
             end = p + n
             while p + 8 <= end and len(self.msgs) < nmsg:
@@ -102,9 +131,12 @@ class _Object:
         w = 1 << (flags & 3)
         size0 = int.from_bytes(buf[p:p + w], "little")
         p += w
-        blocks = [(p, size0)]
+        blocks, seen = [(p, size0)], 0
         track = bool(flags & 0x04)
         while blocks:
+            seen += 1
+            if seen > _MAX_BLOCKS:
+                raise CorruptFile(f"object header at {addr}: continuation blocks do not end")
             p, n = blocks.pop(0)
             end = p + n
             while p + 4 + (2 if track else 0) <= end:
@@ -165,11 +197,17 @@ class Dataset:
     # -- raw bytes of the whole dataset
     def _raw(self):
         buf = self.f.buf
-        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.type.size if self.shape is not None else 0
+        nbytes = int(np.prod([int(d) for d in self.shape], dtype=object)) * self.type.size if self.shape is not None else 0
+        # contiguous / compact data lies inside the file; chunked data may have unwritten chunks, but a shape that asks
+        # for far more than the file could ever hold is a damaged dataspace message, not a dataset
+        if nbytes > (len(buf) if self.layout in (0, 1) else 64 * len(buf) + (1 << 20)):
+            raise CorruptFile(f"{self.name}: shape {self.shape} x {self.type.size} bytes exceeds what the file can hold")
         if self.layout in (0, 1):
             addr, size = self.where
             if addr == UNDEF or nbytes == 0:                 # never written: fill value 0
                 return bytes(nbytes)
+            if addr + nbytes > len(buf):
+                raise CorruptFile(f"{self.name}: data at {addr} + {nbytes} bytes runs past the end of the file")
             return buf[addr:addr + nbytes]
         out = bytearray(nbytes)
         self._chunks(self.chunk_btree, out)
@@ -205,6 +243,7 @@ class Dataset:
         n = raw.size // 16
         return raw.reshape(n, 16)
 
+    @_guard
     def read_ragged(self):
         """Variable-length numeric dataset -> (flat values, lengths int64), one buffer for all elements."""
         if self.type.cls != 9 or self.type.vlen_string:
@@ -231,8 +270,23 @@ class Dataset:
             out[i] = flat[off[i]:off[i + 1]]
         return out.reshape(self.shape)
 
+    @_guard
     def __getitem__(self, idx):
-        a = self._read()
+        # one parse per Dataset object (hf["data"][i] in a loop would otherwise re-read and re-gather the whole dataset
+        # per index); callers get copies of what they index, as from h5py, except for the object arrays' elements
+        a = self.__dict__.get("_read_cache")
+        if a is None:
+            a = self._read()
+            self.__dict__["_read_cache"] = a
+        if isinstance(a, np.ndarray) and a.dtype != object and not (isinstance(idx, tuple) and idx == ()):
+            out = a[idx]
+            return out.copy() if isinstance(out, np.ndarray) else out
+        if isinstance(a, np.ndarray) and a.dtype == object and isinstance(idx, slice):
+            out = a[idx].copy()
+            for i in range(out.size):
+                if isinstance(out.flat[i], np.ndarray):
+                    out.flat[i] = out.flat[i].copy()      # the reference clips the rows it reads in place
+            return out
         if isinstance(idx, tuple) and idx == ():
             return a[()] if a.shape == () else a
         return a[idx]
@@ -313,6 +367,7 @@ class Group:
         except KeyError:
             return False
 
+    @_guard
     def __getitem__(self, name):
         node = self
         for part in [p for p in name.split("/") if p]:
@@ -327,6 +382,14 @@ class File(Group):
         if mode != "r":
             raise ValueError("supernnova_amd.utils.h5reader opens files read-only")
         self._fh = open(path, "rb")
+        try:
+            self._parse(path)
+        except BaseException:
+            self.close()
+            raise
+
+    @_guard
+    def _parse(self, path):
         self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
         self._cache, self._gcol = {}, {}
         base = 0
@@ -357,10 +420,13 @@ class File(Group):
         return False
 
     def close(self):
-        if self.buf is not None:
-            self.buf.close()
-            self._fh.close()
-            self.buf = None
+        buf, self.buf = getattr(self, "buf", None), None
+        if buf is not None:
+            try:
+                buf.close()
+            except BufferError:       # a numpy view of the mapping is still alive (it keeps the pages; the file closes below)
+                pass
+        self._fh.close()
 
     def _open(self, addr, name):
         node = self._cache.get(addr)
@@ -394,7 +460,7 @@ class File(Group):
         tab = self._gcol.get(addr)
         if tab is None:
             buf = self.buf
-            if buf[addr:addr + 4] != b"GCOL":
+            if addr > len(buf) - 16 or buf[addr:addr + 4] != b"GCOL":
                 raise ValueError(f"global heap collection at {addr}: signature missing")
             size, = struct.unpack_from("<Q", buf, addr + 8)
             tab, p = {}, addr + 16
@@ -407,18 +473,29 @@ class File(Group):
             self._gcol[addr] = tab
         return tab
 
-    def _heap_object(self, d):
+    def _heap_object(self, d, elem_size=1):
+        """The `ln` elements a 16-byte vlen record {length, collection address, object index} points to.  The heap
+        object may be longer than ln * elem_size (the heap pads objects to 8 bytes): only the record's length counts."""
         ln, addr, idx = struct.unpack("<IQI", bytes(d))
         if ln == 0 or addr in (0, UNDEF):
             return b""
-        off, size = self._collection(addr)[idx]
-        return bytes(self.buf[off:off + size])
+        try:
+            off, size = self._collection(addr)[idx]
+        except KeyError:
+            raise ValueError(f"vlen element points to heap object {idx}, which collection {addr} does not hold") from None
+        if off + size > len(self.buf):
+            raise ValueError(f"heap object {idx} of collection {addr} runs past the end of the file")
+        return bytes(self.buf[off:off + min(ln * elem_size, size)])
 
     def _vlen_gather(self, desc, base):
         """(n, 16) descriptor records -> (flat values of dtype `base`, lengths).  float32 goes through the native
         helper; other base types through the Python path."""
         lens = desc[:, :4].copy().view("<u4").ravel().astype(np.int64)
+        addrs = desc[:, 4:12].copy().view("<u8").ravel()
+        lens[(addrs == 0) | (addrs == UNDEF)] = 0          # "no heap object": an empty element whatever its length field says
         total = int(lens.sum())
+        if total * np.dtype(base).itemsize > len(self.buf):
+            raise CorruptFile(f"variable-length dataset claims {total} values, more than the file holds")
         flat = np.empty(total, dtype=base)
         if base == np.dtype("<f4") and total:
             try:
@@ -432,11 +509,18 @@ class File(Group):
                 del arr
                 _lib.check(rc, "snn_h5_vlen_gather")
                 return flat, lens
-            except ImportError:
+            except (ImportError, OSError, AttributeError):
+                # no usable libsnn_hip.so on this host (not built, libamdhip64 unresolvable on a CPU-only machine, a stale
+                # build without the symbol): the gather below does the same in Python.  A malformed FILE is not this
+                # case: the native gather reports it as SnnError, which propagates.
                 pass
         off = 0
+        isz = np.dtype(base).itemsize
         for d, n in zip(desc, lens):
             if n:
-                flat[off:off + n] = np.frombuffer(self._heap_object(d), dtype=base, count=n)
+                b = self._heap_object(d, isz)
+                if len(b) != n * isz:
+                    raise ValueError(f"vlen element of {n} values points to a heap object of {len(b)} bytes")
+                flat[off:off + n] = np.frombuffer(b, dtype=base, count=n)
                 off += n
         return flat, lens

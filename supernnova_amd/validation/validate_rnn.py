@@ -220,17 +220,55 @@ def get_predictions_mc(settings, rnn, list_data, peak_mjds=None, times=None, bat
     return tuple(out)
 
 
-def get_predictions_for_speed_benchmark(settings, rnn, list_data):
-    """validate_rnn.py:513-584 without the CSV: supernova_per_s = N / wall time to produce
-    S softmax vectors for every curve, host batching and the device->host copy included."""
+def get_predictions_for_speed_benchmark(settings):
+    """The reference's own definition of the speed metric (validate_rnn.py:513-584), same signature and side effects:
+    load the test list of `settings.processed_dir/database.h5` (tu.load_HDF5(test=True)), build a RANDOMLY INITIALISED
+    model (:535-537), classify every test curve `num_inference_samples` times (1 for a vanilla model) mini-batch by
+    mini-batch of `settings.batch_size` (:540-542), and record
+        Supernova_per_s = num_elem / wall time        (host batching and the device->host copy inside the clock, :544-566)
+    in `settings.stats_dir/rnn_speed.csv` with the columns Supernova_per_s (stored through float16, :569-571), model,
+    batch_size, device, id = "<model>_<batch_size>_<device>"; an existing file has the row with that id replaced or
+    appended, anything unreadable is overwritten (:578-584).
+    What differs is inside a mini-batch: the S forwards of the reference's inner loop (:559-563) are ONE launch
+    (predict_mc) whose (B, S, C) probabilities are copied to the host once -- batch_size stays the caller's knob
+    ("Batch size can be controled to speed up predictions"): one batch holding the whole test set is one launch.
+    Returns Supernova_per_s (the reference returns None)."""
+    import os
+    import pandas as pd
     settings.random_length = False
-    S = 1 if settings.model == "vanilla" else settings.num_inference_samples
+    if "vanilla" in settings.pytorch_model_name:
+        settings.num_inference_samples = 1
+    list_data_test = tu.load_HDF5(settings, test=True)
+    rnn = tu.get_model(settings, len(settings.training_features))
+    rnn.to(settings.device)
     rnn.eval()
-    start = time()
-    with torch.no_grad():
-        probs = predict_mc(rnn, [d[0] for d in list_data], S).cpu().numpy()
-    total = time() - start
-    return len(list_data) / total, probs
+    num_elem = len(list_data_test)
+    num_batches = num_elem / min(num_elem, settings.batch_size)
+    list_batches = np.array_split(np.arange(num_elem), int(num_batches))      # (array_split truncates the reference's float the same way)
+    curves = [d[0] for d in list_data_test]
+    start_time = time()
+    for batch_idxs in list_batches:
+        with torch.no_grad():
+            arr_preds = predict_mc(rnn, [curves[k] for k in batch_idxs], settings.num_inference_samples,
+                                   device=torch.device(settings.device)).cpu().numpy()
+    total_time = time() - start_time
+    assert arr_preds.shape[1:] == (settings.num_inference_samples, settings.nb_classes)
+    supernova_per_s = num_elem / total_time
+    model_id = f"{settings.model}_{settings.batch_size}_{settings.device}"
+    df = pd.DataFrame(data=np.array([supernova_per_s]).astype(np.float16), columns=["Supernova_per_s"])
+    df["model"] = settings.model
+    df["batch_size"] = settings.batch_size
+    df["device"] = settings.device
+    df["id"] = model_id
+    os.makedirs(str(settings.stats_dir), exist_ok=True)
+    results_file = os.path.join(str(settings.stats_dir), "rnn_speed.csv")
+    try:
+        df_all = pd.read_csv(results_file, index_col="id")
+        df_all.loc[model_id] = df.set_index("id").loc[model_id]
+        df_all.reset_index().to_csv(results_file, index=False)
+    except Exception:
+        df.to_csv(results_file, index=False)
+    return supernova_per_s
 
 
 def flatten_to_dataframe(pred_dict):

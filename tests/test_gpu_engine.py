@@ -431,8 +431,10 @@ def test_gru_rnn_vs_oracle_ragged(cell, D, H, L, bidir, C, pool):
         _check(lo[s], pr[s], o["logits"], o["probs"])
 
 
-def test_gru_rnn_are_inference_only():
-    """The training / Bayesian / split-precision entry points refuse the GRU and RNN cells with a clear error."""
+def test_gru_rnn_cells_refuse_what_they_do_not_implement():
+    """GRU / tanh-RNN cells run inference and training (tests/test_gpu_train.py), but have no Bayes-by-Backprop path
+    (bayesian_rnn.py:47-69 registers the LSTM only), no split-precision kernel and no masked *inference* kernel: those
+    entry points refuse the cells with a clear error instead of computing something else."""
     E = _eng()
     from supernnova_amd import _lib as L
     cfg = E.Config(24, 32, 2, True, 2, "mean", cell="gru")

@@ -1,0 +1,60 @@
+"""GPU: a13, validate_rnn.get_predictions_for_speed_benchmark(settings) with the reference's signature and side effects
+(validation/validate_rnn.py:513-584): test list from <processed_dir>/database.h5 (written by tests/h5writer.py, read by
+the package's reader through tu.load_HDF5), randomly initialised model, timed MC loop, stats/rnn_speed.csv with the
+reference's columns and its update-or-create behaviour."""
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from test_host_logic import settings
+
+pytestmark = pytest.mark.gpu
+
+
+def _speed_settings(tmp_path, model, batch_size):
+    from h5writer import write_database
+    from test_h5reader import _file_db
+    from util import loader_settings
+    out, _, feats = _file_db()
+    if not (tmp_path / "database.h5").exists():
+        write_database(str(tmp_path / "database.h5"), out)
+    ls = loader_settings(feats)
+    st = settings(model=model, use_cuda=True, batch_size=batch_size, num_inference_samples=9, device="cuda",
+                  pytorch_model_name=f"{model}_S_0_CLF_2", stats_dir=str(tmp_path / "stats"), random_length=True)
+    st.__dict__.update(ls.__dict__)
+    st.processed_dir = str(tmp_path)
+    return st
+
+
+def test_speed_benchmark_writes_and_updates_rnn_speed_csv(tmp_path):
+    from supernnova_amd.utils import training_utils as tu
+    from supernnova_amd.validation import validate_rnn as vr
+    torch.manual_seed(0)
+    csv = tmp_path / "stats" / "rnn_speed.csv"
+    rates = {}
+    # three models, reference signature: ONE argument; the CSV is created by the first call and extended by the others
+    for model, bs in (("bayesian", 8), ("variational", 128), ("vanilla", 8)):
+        st = _speed_settings(tmp_path, model, bs)
+        n_test = len(tu.load_HDF5(st, test=True))
+        rates[model] = vr.get_predictions_for_speed_benchmark(st)
+        assert st.random_length is False                                    # validate_rnn.py:526
+        assert st.num_inference_samples == (1 if model == "vanilla" else 9)  # :528-529
+        assert rates[model] > 0 and n_test > 8                              # several mini-batches at batch_size 8
+    df = pd.read_csv(csv)
+    assert list(df.columns) == ["id", "Supernova_per_s", "model", "batch_size", "device"]      # after the first update (:580-582)
+    assert list(df["id"]) == ["bayesian_8_cuda", "variational_128_cuda", "vanilla_8_cuda"]
+    assert list(df["model"]) == ["bayesian", "variational", "vanilla"] and list(df["batch_size"]) == [8, 128, 8]
+    for model, v in rates.items():
+        got = float(df.set_index("model").loc[model, "Supernova_per_s"])
+        assert got == float(np.float16(v)), (model, got, v)                  # stored through float16 (:569-571)
+    # same id again: the row is replaced, not appended (:580-582)
+    st = _speed_settings(tmp_path, "bayesian", 8)
+    v2 = vr.get_predictions_for_speed_benchmark(st)
+    df2 = pd.read_csv(csv)
+    assert len(df2) == 3 and float(df2.set_index("id").loc["bayesian_8_cuda", "Supernova_per_s"]) == float(np.float16(v2))
+    # an unreadable file is overwritten by a fresh one-row frame with the reference's column order (:583-584)
+    csv.write_text("garbage\n\x00\x01")
+    vr.get_predictions_for_speed_benchmark(st)
+    df3 = pd.read_csv(csv)
+    assert list(df3.columns) == ["Supernova_per_s", "model", "batch_size", "device", "id"] and len(df3) == 1
