@@ -460,6 +460,9 @@ def main():
                          "several minutes of CPU work")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the two secondary workloads (variational, elasticc) the default run appends as `secondary`")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training measurements (BASELINE configs[3]) the default run appends as secondary.train "
+                         "and a --gpus N run as train_dp")
     ap.add_argument("--no-fast-path", action="store_true",
                     help="skip the extra f16x2 measurement the default (f32, des, 1 GPU) run appends as `fast_path`")
     ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2"], default="f32",
@@ -505,10 +508,51 @@ def main():
             sub = run(a2, rank, world, dev, backend, None)
             out["secondary"][wl] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "steps", "roofline")}
             out["secondary"][wl]["workload"] = sub["config"]["workload"]
+    # BASELINE configs[3], BayesianRNN training (fwd with tape + CE + BPTT + BBB/KL backward + fused Adam), in the line
+    # the driver records: single rank -> secondary.train at the reference's own batch size (128, conf.py:517) and at a
+    # batch that fills the chip; N ranks -> train_dp, data parallel over RCCL with ONE all-reduce of the flat gradient
+    # per step, at a global batch of 128 (the reference's step split N ways: 128 / N curves per rank) and of 128 per rank.
+    if not args.no_train and not os.environ.get("SNN_BENCH_NOCHECK") and args.workload == "des" and args.precision == "f32":
+        import bench_train
+        torch.cuda.empty_cache()
+
+        def train_obj(per_rank, steps, warmup):
+            a = bench_train.parser().parse_args([])
+            a.gpus, a.batch, a.steps, a.warmup, a.cpu_steps = world, per_rank, steps, warmup, 0
+            r = bench_train.measure(a, rank, world, dev, backend)
+            if r is None:
+                return None
+            o = {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "n_gpus")}
+            o["global_batch"] = r["config"]["global_batch"]
+            o["workload"] = r["config"]["workload"]
+            rf = r.get("roofline")
+            if rf:
+                o["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "flop_per_step",
+                                                    "isolated_step_ms", "phases_ms", "forward", "backward",
+                                                    "forward_kernel", "backward_path")}
+            return o
+
+        if world == 1 and default_run:
+            tr = {"b128": train_obj(128, 200, 30), "b65536": train_obj(65536, 10, 3)}
+            out.setdefault("secondary", {})["train"] = tr
+        elif world > 1:
+            per = max(1, 128 // world)
+            tr = {f"global_b{per * world}": train_obj(per, 200, 30), f"global_b{128 * world}": train_obj(128, 200, 30)}
+            if rank == 0:
+                for o in tr.values():
+                    o["backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
+                    o["allreduce_bytes"] = 4 * (2 * E_param_count() - 2)
+                    o["allreduce_plus_adam_ms"] = (o.get("roofline") or {}).get("phases_ms", {}).get("allreduce+adam")
+                out["train_dp"] = tr
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def E_param_count():
+    from supernnova_amd import engine as E
+    return E.Config(24, 32, 2, True, 2, "mean").P
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def settings(**kw):
     return SimpleNamespace(**d)
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -47,12 +47,41 @@ def main():
     ap.add_argument("--features", type=int, default=24, help="input width D (24: 4 filters; 78: 6 filters + redshift)")
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--max-len", type=int, default=40)
+    ap.add_argument("--layer-type", default="lstm", choices=["lstm", "gru", "rnn"], help="VanillaRNN only for gru / rnn")
     ap.add_argument("--full-length", action="store_true", help="every curve has max-len steps (configs[4]: 300)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = parser().parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench_train.py --gpus N`: one fresh process per GPU, started before anything touches the GPU
         from supernnova_amd.distributed import self_launch
         raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
+    # correctness only -- the gradient all-reduce is staged through the host, see distributed.allreduce_mean_scale)
+    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from supernnova_amd import distributed as D
+    D.init_from_env(backend, dev)
+    out = measure(args, rank, world, dev, backend)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def measure(args, rank, world, dev, backend):
+    """Warm-up + timed training steps of one configuration on an initialised process group (bench.py calls this for
+    the `train` / `train_dp` objects of its line); returns the result dict on rank 0, None elsewhere."""
     # SNN_BENCH_WATCHDOG=<seconds>: INACTIVITY limit, re-armed after init and after every step, so a stuck rank prints
     # where it is and exits while slow progress does not trip it; SNN_BENCH_TRACE=1 prints a time stamp per step
     wd = int(os.environ.get("SNN_BENCH_WATCHDOG", "0"))
@@ -67,25 +96,12 @@ def main():
                   file=sys.stderr, flush=True)
     t_start = time.perf_counter()
     alive("start")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # SNN_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices;
-    # correctness only -- the gradient all-reduce is staged through the host, see distributed.allreduce_mean_scale)
-    backend = os.environ.get("SNN_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     from supernnova_amd import distributed as D
     from supernnova_amd.utils import training_utils as tu
-    D.init_from_env(backend, dev)
     alive("process group up")
 
     st = settings(model=args.model, weight_decay=1e-7 if args.model == "variational" else 0.0,
-                  hidden_dim=args.hidden, nb_classes=args.classes)
+                  hidden_dim=args.hidden, nb_classes=args.classes, layer_type=getattr(args, "layer_type", "lstm"))
     Dw = args.features
     torch.manual_seed(0)                       # identical init and identical Philox seeds on every rank
     rnn = tu.get_model(st, Dw).to(dev)
@@ -147,17 +163,19 @@ def main():
                 acc[name] = acc.get(name, 0.0) + a.elapsed_time(b) / n_ph
         rnn._timeline = None
         phases = acc
+    out = None
     if rank == 0:
         out = {"metric": f"light curves/s trained, {args.model} RNN (fwd + ELBO/KL bwd + Adam), data-parallel",
                "value": gB * args.steps / dt, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"{args.model} LSTM {args.hidden}x2 bidirectional D={Dw} C={args.classes}, batch {B} per GPU, "
+               "config": {"workload": f"{args.model} {getattr(args, 'layer_type', 'lstm').upper()} {args.hidden}x2 bidirectional D={Dw} C={args.classes}, batch {B} per GPU, "
                                       + (f"{T}-step sequences, " if args.full_length else f"lengths U{{3..{T}}}, ") +
                                       f"path={args.path}", "global_batch": gB, "parallelism": f"dp{world}"}}
         # algorithmic FLOPs: 3 x F_fwd per curve per step, F_fwd = l * 16H(D+4H) + 4HC (L=2, bidirectional)
         H, C = args.hidden, args.classes
-        f_fwd = float(lengths.astype(np.int64).sum()) * 16 * H * (Dw + 4 * H) + B * 4 * H * C
+        NG = {"lstm": 4, "gru": 3, "rnn": 1}[getattr(args, "layer_type", "lstm")]      # gate blocks per hidden unit
+        f_fwd = float(lengths.astype(np.int64).sum()) * 4 * NG * H * (Dw + 4 * H) + B * 4 * H * C
         PEAK = 157.3      # fp32 MFMA TFLOP/s (MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32)
         if phases is not None:
             # achieved = this rank's algorithmic FLOPs per step / the step time of the TIMED loop (back-to-back steps: the
@@ -165,7 +183,9 @@ def main():
             # synchronisation after each, so their sum is the latency of ONE isolated step, host gaps included.
             ach = 3 * f_fwd / (dt / args.steps) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "whole fused step, timed loop (phases below: isolated steps; per-kernel times: profiles/r2/)",
+                "bound": "mfma", "kernel": "whole fused step, timed loop (phases below: isolated steps; per-kernel times: profiles/)",
+                "forward_kernel": __import__("supernnova_amd.engine", fromlist=["x"]).last_forward_kernel(),
+                "backward_path": (__import__("supernnova_amd._lib", fromlist=["x"]).load().snn_last_backward_path() or b"").decode(),
                 "achieved": ach, "peak": PEAK, "unit": "TFLOP/s", "frac": ach / PEAK, "traffic": None,
                 "flop_per_step": 3 * f_fwd, "isolated_step_ms": sum(phases.values()),
                 "phases_ms": phases,
@@ -189,9 +209,8 @@ def main():
             out["cpu_baseline"] = {"value": B * args.cpu_steps / cdt, "unit": "light curves/s",
                                    "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"{args.cpu_steps} train steps of the same batch on the stock-PyTorch port"}
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    return out
 
 
 if __name__ == "__main__":

@@ -224,14 +224,14 @@ __global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ te
 // Head of the per-layer training forward (lstm_fwd_train_layer_kernel): per curve, the per-wave partial logits of the
 // phases that feed the head, added in the persistent kernel's order ((l, d) outer, wave inner, from 0.0f), then bias
 // (+ softmax): the same fp32 additions, so the same bits.
-__global__ void __launch_bounds__(64) head_combine_kernel(const FwdParams p, int H, int dirs, int64_t k_head_b,
+__global__ void __launch_bounds__(64) head_combine_kernel(const FwdParams p, int NW, int dirs, int64_t k_head_b,
                                                          const float* __restrict__ head_part)
 {
     const int tile = blockIdx.x, cl = threadIdx.x;
     if (cl >= 32) return;
     const int orig = p.order[tile * SNN_TILE + cl];
     if (orig < 0) return;
-    const int NW = H / 8, n_ld = p.L * dirs;
+    const int n_ld = p.L * dirs;     // NW: per-wave partials per phase (H / 8 waves; 4 in the H = 128 kernels)
     const float* bo = p.wk + k_head_b;
     const int64_t o = (int64_t)orig * p.os_n;
     float mx = -INFINITY;
@@ -266,8 +266,14 @@ extern "C" const char* snn_last_forward_kernel(void) { return g_last_kernel; }
 // ---- forward kernel registry ----------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; };
-struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; fwd_layer_kernel_t fn_train_layer; };
+typedef void (*fwd_rec_kernel_t)(const FwdParams, int, float*, const float*);
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; fwd_rec_kernel_t fn_rec[3]; };
+struct FwdEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train; bool big; fwd_layer_kernel_t fn_train_layer; fwd_rec_kernel_t fn_rec; };
+fwd_rec_kernel_t snn_big_rec_kernel(int H, int KKI0, int dirs);   // snn_forward_big.hip
+// snn_fwd_gx.hip: the input half of a training forward as one launch over the chip
+bool snn_gx_supported(const SnnLayout& y);
+int64_t snn_gx_floats(const SnnLayout& y, int n_tiles, int max_T);
+int snn_launch_gx(const SnnLayout& y, const FwdParams& p, int l, float* gx, int cus, hipStream_t st);
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
@@ -284,17 +290,18 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
                            : y.H == 64 ? snn_fwd_small_h64(y.KKI[0], y.dirs) : nullptr;
     if (e && y.cell != 0) {   // GRU / tanh RNN: un-masked inference kernel + the training kernel (which takes masks)
         ent = FwdEntry{e->H, e->KKI0, e->dirs, y.cell == 1 ? e->fn_gru : e->fn_rnn, nullptr,
-                       y.cell == 1 ? e->fn_gru_train : e->fn_rnn_train, false, nullptr};
+                       y.cell == 1 ? e->fn_gru_train : e->fn_rnn_train, false, nullptr, e->fn_rec[y.cell]};
         return &ent;
     }
     if (y.cell != 0) return nullptr;
     if (e) {
-        ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false, e->fn_train_layer};
+        ent = FwdEntry{e->H, e->KKI0, e->dirs, e->fn, e->fn_masked, e->fn_train, false, e->fn_train_layer, e->fn_rec[0]};
         return &ent;
     }
     // hidden sizes whose weights do not fit the register file: two-pass kernel
     if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, false)) {
-        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true, nullptr};
+        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true, nullptr,
+                       snn_big_rec_kernel(y.H, y.KKI[0], y.dirs)};
         return &ent;
     }
     return nullptr;
@@ -714,8 +721,36 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     // 65 536: 1.55 / 1.40 / 1.30; 131 072: 3.06 / 2.72 / 2.63): independent workgroups leave the balancing to the
     // dispatcher and run the two directions side by side.  The persistent kernel remains for unidirectional models,
     // the GRU / tanh-RNN cells and batches whose head partials do not fit the workspace.
-    const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * y.NW * y.C * 32;
+    const int n_part = e->big ? 4 : y.NW;      // per-wave head partials per phase
+    const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * n_part * y.C * 32;
     const bool no_layerwise = getenv("SNN_NO_LAYERWISE") != nullptr;   // A/B measurements and tests (read per call)
+    // Small batches: input products of a whole layer in one launch over the chip (fwd_gx_kernel), then the recurrent
+    // half with a workgroup per (tile, direction) -- the dependent chain per step shrinks to the H / 2 recurrent k-steps.
+    // Chosen while every (tile, direction) gets a compute unit to itself; SNN_FWD_SPLIT=0|1 forces it off / on (A/B,
+    // tests).  Results are bit-identical to the other training forwards.
+    {
+        const char* force = getenv("SNN_FWD_SPLIT");
+        const int64_t gx_bytes = (int64_t)sizeof(float) * snn_gx_floats(y, n_tiles, max_T);
+        const int64_t part_off = 256, gx_off = (part_off + part_bytes + 255) & ~(int64_t)255;
+        const bool want = force ? force[0] == '1' : (int64_t)n_tiles * y.dirs <= g.cus;
+        if (train && e->fn_rec && want && !no_layerwise && snn_gx_supported(y) && gx_off + gx_bytes <= workspace_bytes) {
+            float* head_part = (float*)((char*)workspace + part_off);
+            float* gx = (float*)((char*)workspace + gx_off);
+            const size_t lds = e->big ? sizeof(float) * ((size_t)3 * y.H * 32 + (size_t)5 * y.C * 32) + 16
+                                      : sizeof(float) * ((size_t)2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
+            HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_rec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "fwd_gx_kernel + %s<%d,%d,%d,cell%d> x %d layers grid=%d block=%d lds=%zu",
+                     e->big ? "lstm_fwd_big_rec_kernel" : "lstm_fwd_rec_kernel", y.H, y.KKI[0], y.dirs, y.cell, y.L,
+                     n_tiles * y.dirs, g.threads, lds);
+            for (int l = 0; l < y.L; ++l) {
+                if ((rc = snn_launch_gx(y, p, l, gx, g.cus, st))) return rc;
+                hipLaunchKernelGGL(e->fn_rec, dim3(n_tiles * y.dirs), dim3(g.threads), lds, st, p, l, head_part, (const float*)gx);
+            }
+            hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, n_part, y.dirs, y.k_head_b, head_part);
+            HIP_CHECK(hipGetLastError());
+            return SNN_OK;
+        }
+    }
     if (train && e->fn_train_layer && !no_layerwise && 256 + part_bytes <= workspace_bytes) {
         float* head_part = (float*)((char*)workspace + 256);
         HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_train_layer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
@@ -723,7 +758,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                  y.H, y.KKI[0], y.dirs, y.L, n_tiles * y.dirs, g.threads, g.lds);
         for (int l = 0; l < y.L; ++l)
             hipLaunchKernelGGL(e->fn_train_layer, dim3(n_tiles * y.dirs), dim3(g.threads), g.lds, st, p, l, head_part);
-        hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, y.H, y.dirs, y.k_head_b, head_part);
+        hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, y.NW, y.dirs, y.k_head_b, head_part);
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }

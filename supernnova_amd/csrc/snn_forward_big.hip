@@ -19,7 +19,8 @@
 #include "snn_host.h"
 
 // One (layer, direction) phase.  TP = row tiles per wave handled by one input pass.
-template <int H, int KKI, int DIRS, bool FIRST, int TP, bool TRAIN>
+// GX: pass 1 was done by fwd_gx_kernel (snn_fwd_gx.hip) for all tiles at once; `gx` is this (tile, direction)'s block.
+template <int H, int KKI, int DIRS, bool FIRST, int TP, bool TRAIN, bool GX = false>
 __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
                                           int k_head_w, float* xin, float* hb, float* part, float* logit,
                                           float* mlds, float* gx)
@@ -47,7 +48,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     for (int i = 0; i < NPT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
-    if (masked && (FIRST || (TRAIN && !mid_step))) {
+    if (!GX && masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
 #ifdef SNN_ABL_BIG_NOP1   // timing ablation only (results are wrong): the recurrent pass alone
     if (p.n_curves >= 0) goto pass2;
 #endif
-    for (int r0 = 0; r0 < RT; r0 += TP) {
+    for (int r0 = 0; r0 < (GX ? 0 : RT); r0 += TP) {
         float wx[TP][KKI];
         f32x16 binit[TP];
 #pragma unroll
@@ -392,6 +393,63 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
     }
 }
 
+// ---- training forward of ONE layer from precomputed input products: a workgroup per (tile, direction) -----------
+// The persistent kernel above walks a tile's L * DIRS phases one after the other and, per phase, the input pass
+// before the recurrent one: 128 curves x 300 steps at H = 128 are 4 workgroups x 4 phases x (2 + 1) x 300 dependent
+// steps = 28 ms on 4 of 256 compute units.  Here the input pass of a whole layer is ONE launch over the chip
+// (fwd_gx_kernel), the two directions of a layer run side by side, and the chain per layer is 300 recurrent steps.
+// Same accumulation order (bias + input k-steps, then recurrent k-steps): bit-identical tape and logits.
+template <int H, int KKI0, int DIRS>
+__global__ void __launch_bounds__(256, 1) lstm_fwd_big_rec_kernel(const FwdParams p, int l, float* __restrict__ head_part,
+                                                                 const float* __restrict__ gx)
+{
+    constexpr int NT = 256;
+    constexpr int KKI1 = DIRS * H / 2;
+    constexpr int NWT = H / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdParams& y = p;
+    constexpr int BLK0 = NWT * (KKI0 + H / 2) * 64 + 2 * NWT * 32;
+    constexpr int BLK1 = NWT * (KKI1 + H / 2) * 64 + 2 * NWT * 32;
+    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
+    float* hb = smem;                      // [2][H*32]
+    float* mlds = hb + 2 * H * 32;         // [H*32] (inference only; unused here)
+    float* part = mlds + H * 32;           // [4][C][32]
+    float* logit = part + 4 * y.C * 32;    // [C][32]
+
+    ItemCtx c;
+    c.tid = threadIdx.x;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.cl = c.lane & 31;
+    c.hf = c.lane >> 5;
+    c.ybase = nullptr;
+    c.tile = blockIdx.x / DIRS;
+    const int d = blockIdx.x - c.tile * DIRS;
+    c.s = 0;
+    c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+    const int pos = c.tile * SNN_TILE + c.cl;
+    c.len = p.len_sorted[pos];
+    c.orig = p.order[pos];
+    c.wks = p.wk;
+    c.tape = p.tape + (int64_t)c.tile * p.tape_tile;
+    float* gxb = const_cast<float*>(gx) + ((int64_t)c.tile * DIRS + d) * p.max_T * (4 * H * 32);
+    for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
+    __syncthreads();
+    if (l == 0) {
+        const int kA = d * BLK0;
+        big_phase<H, KKI0, DIRS, true, 1, true, true>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64, k_head_w, nullptr, hb, part,
+                                                      logit, mlds, gxb);
+    } else {
+        const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
+        big_phase<H, KKI1, DIRS, false, 1, true, true>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64, k_head_w, nullptr, hb, part,
+                                                       logit, mlds, gxb);
+    }
+    if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {   // per-wave head partials of this phase, for head_combine_kernel
+        float* dst = head_part + ((int64_t)c.tile * (y.L * DIRS) + l * DIRS + d) * (4 * y.C * 32);
+        for (int idx = c.tid; idx < 4 * y.C * 32; idx += NT) dst[idx] = part[idx];
+    }
+}
+
 // ---- registry hooks used by snn_forward.hip -------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 #define BIG_PICK(K, Dd) if (KKI0 == K && dirs == Dd) return train ? lstm_fwd_big_kernel<128, K, Dd, true> : lstm_fwd_big_kernel<128, K, Dd, false>
@@ -400,5 +458,14 @@ fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train)
     if (H != 128) return nullptr;
     BIG_PICK(12, 2); BIG_PICK(13, 2); BIG_PICK(24, 2); BIG_PICK(38, 2); BIG_PICK(39, 2);   // D <= 24, 26, 48, 76, 78
     BIG_PICK(12, 1); BIG_PICK(13, 1); BIG_PICK(24, 1); BIG_PICK(38, 1); BIG_PICK(39, 1);
+    return nullptr;
+}
+typedef void (*fwd_rec_kernel_t)(const FwdParams, int, float*, const float*);
+#define BIG_REC_PICK(K, Dd) if (KKI0 == K && dirs == Dd) return lstm_fwd_big_rec_kernel<128, K, Dd>
+fwd_rec_kernel_t snn_big_rec_kernel(int H, int KKI0, int dirs)
+{
+    if (H != 128) return nullptr;
+    BIG_REC_PICK(12, 2); BIG_REC_PICK(13, 2); BIG_REC_PICK(24, 2); BIG_REC_PICK(38, 2); BIG_REC_PICK(39, 2);
+    BIG_REC_PICK(12, 1); BIG_REC_PICK(13, 1); BIG_REC_PICK(24, 1); BIG_REC_PICK(38, 1); BIG_REC_PICK(39, 1);
     return nullptr;
 }

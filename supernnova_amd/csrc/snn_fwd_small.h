@@ -27,7 +27,9 @@ struct PhaseCfg {
 //   TRAIN: activations go to the tape (which also carries the layer outputs, unmasked; the
 //          between-layer mask is then applied by the consumer while staging).
 //   CELL:  0 LSTM, 1 GRU, 2 tanh RNN (snn_layout.h: the weight image has the LSTM's 4 row groups for every cell).
-template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED, int CELL = 0>
+//   GX:    the input half (bias + W_ih x_t) of every step was computed by fwd_gx_kernel (snn_fwd_gx.hip) and is read
+//          from c.gx; the step then issues only the H / 2 recurrent k-steps (small batches: a shorter dependent chain).
+template <int H, int KKI, int DIRS, bool FIRST, bool TRAIN, bool MASKED, int CELL = 0, bool GX = false>
 __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
                                           int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
 {
@@ -47,7 +49,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     {
         const float* A = c.wks + k_A + c.w * KK * 64 + c.lane;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];
+        for (int kk = GX ? KKI : 0; kk < KK; ++kk) wreg[kk] = A[kk * 64];   // GX: the recurrent columns only
     }
     // variational W_hh row mask: forward direction only (variational_rnn.py:45, 224-238)
     if (d == 0 && masked) {
@@ -57,7 +59,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
     }
     // b_ih + b_hh in C/D register order, parked in LDS (re-read per step: 4 broadcast ds_read_b128)
-    if (c.cl < 16) {
+    if (!GX && c.cl < 16) {
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
         bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
     }
@@ -78,7 +80,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     for (int i = 0; i < NPT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) min_[i][e] = 1.0f;
-    if (masked && (FIRST || (TRAIN && !mid_step))) {
+    if (!GX && masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = c.tid + i * NT;
@@ -149,11 +151,19 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 
     // ---- state
     float cst[4] = {0.f, 0.f, 0.f, 0.f}, hst[4] = {0.f, 0.f, 0.f, 0.f}, hsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // GX: Gx[t][wave's row tile][16][64] of this (tile, direction), fetched one step ahead of its use
+    const float* gxw = GX ? c.gx + (int64_t)c.w * 1024 + c.lane : nullptr;
+    f32x16 gxn;
     {
-        f32x4 pre[NPT];
         const int t0 = d == 0 ? 0 : T - 1;
-        load_step(t0, pre);
-        store_step(xin, pre, t0);
+        if (GX) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)t0 * NW * 1024 + i * 64];
+        } else {
+            f32x4 pre[NPT];
+            load_step(t0, pre);
+            store_step(xin, pre, t0);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) hb[(j0 + u) * 32 + c.cl] = 0.0f;
     }
@@ -165,13 +175,22 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         f32x4 pre[NPT];
         const bool more = step + 1 < T;
         const int tn = d == 0 ? t + 1 : t - 1;
-        if (more) load_step(tn, pre);
+        if (!GX && more) load_step(tn, pre);
 
-        f32x16 acc = *binit_p;
-        const float* xc = xin + cur * XIN_STRIDE + c.lane;
+        f32x16 acc;
+        if (GX) {
+            acc = gxn;
+            if (more) {
 #pragma unroll
-        for (int kk = 0; kk < KKI; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], xc[kk * 64], acc, 0, 0, 0);
+                for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];
+            }
+        } else {
+            acc = *binit_p;
+            const float* xc = xin + cur * XIN_STRIDE + c.lane;
+#pragma unroll
+            for (int kk = 0; kk < KKI; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], xc[kk * 64], acc, 0, 0, 0);
+        }
         const float* hc = hb + cur * (H * 32) + c.lane;
 #pragma unroll
         for (int kk = 0; kk < KKH; ++kk)
@@ -240,7 +259,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             }
             }
         }
-        if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
+        if (!GX && more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
         lds_barrier();
     }
 
@@ -437,10 +456,64 @@ lstm_fwd_train_layer_kernel(const FwdParams p, int l, float* __restrict__ head_p
     }
 }
 
+// ---- training forward of ONE layer from precomputed input products: the recurrent half ------------------------
+// lstm_fwd_train_layer_kernel with the input k-steps taken out of the step (GX): fwd_gx_kernel (snn_fwd_gx.hip) has
+// written Gx[t] = b + W_ih x_t for every step of every (tile, direction); a step here is H / 2 recurrent MFMAs + the
+// cell.  Chosen for small batches (snn_forward.hip), where the step chain IS the run time: H = 32: 16 MFMAs per step
+// instead of 28 (layer 0) / 48 (layer 1).  Same products in the same order: bit-identical logits and tape.
+template <int H, int KKI0, int DIRS, int CELL>
+__global__ void __launch_bounds__(H * 8, SNN_TRAIN_LAYER_OCC * 32 / H > 0 ? SNN_TRAIN_LAYER_OCC * 32 / H : 1)
+lstm_fwd_rec_kernel(const FwdParams p, int l, float* __restrict__ head_part, const float* __restrict__ gx)
+{
+    constexpr int NT = H * 8;
+    constexpr int KKI1 = DIRS * H / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const FwdParams& y = p;
+    constexpr int NW = H / 8;
+    constexpr int BLK0 = NW * (KKI0 + H / 2) * 64 + 2 * NW * 32;
+    constexpr int BLK1 = NW * (KKI1 + H / 2) * 64 + 2 * NW * 32;
+    const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
+    float* hb = smem;                    // [2][H*32]
+    float* part = hb + 2 * H * 32;       // [NW][C][32]
+    float* logit = part + NW * y.C * 32; // [C][32]
+
+    ItemCtx c;
+    c.tid = threadIdx.x;
+    c.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.cl = c.lane & 31;
+    c.hf = c.lane >> 5;
+    c.ybase = nullptr;
+    c.tile = blockIdx.x / DIRS;
+    const int d = blockIdx.x - c.tile * DIRS;
+    c.s = 0;
+    c.T = __builtin_amdgcn_readfirstlane(p.tile_T[c.tile]);
+    const int pos = c.tile * SNN_TILE + c.cl;
+    c.len = p.len_sorted[pos];
+    c.orig = p.order[pos];
+    c.wks = p.wk;
+    c.tape = p.tape + (int64_t)c.tile * p.tape_tile;
+    c.gx = gx + ((int64_t)c.tile * DIRS + d) * p.max_T * (4 * H * 32);
+    for (int idx = c.tid; idx < y.C * 32; idx += NT) logit[idx] = 0.0f;
+    __syncthreads();
+    if (l == 0) {
+        const int kA = d * BLK0;
+        run_phase<H, KKI0, DIRS, true, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, nullptr, hb, part, logit, nullptr);
+    } else {
+        const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
+        run_phase<H, KKI1, DIRS, false, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, nullptr, hb, part, logit, nullptr);
+    }
+    if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {
+        float* dst = head_part + ((int64_t)c.tile * (y.L * DIRS) + l * DIRS + d) * (NW * y.C * 32);
+        for (int idx = c.tid; idx < NW * y.C * 32; idx += NT) dst[idx] = part[idx];
+    }
+}
+
 // ---- instantiation lists ------------------------------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
 typedef void (*fwd_layer_kernel_t)(const FwdParams, int, float*);
-struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; };
+typedef void (*fwd_rec_kernel_t)(const FwdParams, int, float*, const float*);
+struct FwdSmallEntry { int H, KKI0, dirs; fwd_kernel_t fn, fn_masked, fn_train, fn_gru, fn_rnn, fn_gru_train, fn_rnn_train; fwd_layer_kernel_t fn_train_layer; fwd_rec_kernel_t fn_rec[3]; };
 template <int H, int K, int Dd>
 constexpr fwd_layer_kernel_t train_layer_kernel()
 {
@@ -451,7 +524,8 @@ constexpr fwd_layer_kernel_t train_layer_kernel()
     {H, K, Dd, lstm_fwd_kernel<H, K, Dd, false, false>, lstm_fwd_kernel<H, K, Dd, false, true>, \
      lstm_fwd_kernel<H, K, Dd, true, true>, lstm_fwd_kernel<H, K, Dd, false, false, 1>,         \
      lstm_fwd_kernel<H, K, Dd, false, false, 2>, lstm_fwd_kernel<H, K, Dd, true, true, 1>,      \
-     lstm_fwd_kernel<H, K, Dd, true, true, 2>, train_layer_kernel<H, K, Dd>()}
+     lstm_fwd_kernel<H, K, Dd, true, true, 2>, train_layer_kernel<H, K, Dd>(),                   \
+     {lstm_fwd_rec_kernel<H, K, Dd, 0>, lstm_fwd_rec_kernel<H, K, Dd, 1>, lstm_fwd_rec_kernel<H, K, Dd, 2>}}
 // layer-0 k-step buckets of snn_layout.h (D <= 24, 26, 48, 76, 78), both direction counts
 #define SNN_FWD_ENTRIES(H)                                                                              \
     SNN_FWD_ENTRY(H, 12, 2), SNN_FWD_ENTRY(H, 13, 2), SNN_FWD_ENTRY(H, 24, 2), SNN_FWD_ENTRY(H, 38, 2), \

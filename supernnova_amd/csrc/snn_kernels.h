@@ -206,6 +206,7 @@ struct ItemCtx {
     const float* wks;       // weight set of this sample
     float* ybase;           // this workgroup's y scratch
     float* tape;            // TRAIN: this tile's tape
+    const float* gx;        // GX kernels: input products b + W_ih x_t of this (tile, direction), [t][H/8][16][64]
 };
 
 // host-side mask validation / conversion (snn_forward.hip)

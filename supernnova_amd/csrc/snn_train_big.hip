@@ -330,7 +330,11 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
 }
 
 // ---- weight gradients -----------------------------------------------------------------------------------
-template <int H, int NTN_MAX>
+// NTN = column tiles of [h_prev | x_t | 1] (ceil((H + I + 1) / 32)) is a template parameter: with a run-time tile count
+// and accumulators for the widest layer, every MFMA of the loop sat behind a branch and the compiler kept the
+// accumulators in scratch memory (2.3 KB per lane at H = 128: 857 scratch instructions per tile-step, 4.8 ms per
+// layer for 128 curves x 300 steps -- 20 x the MFMA time).  One instantiation per (H, NTN) that occurs.
+template <int H, int NTN>
 __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int l, int n_chunks)
 {
     constexpr int MG = 4 * H / 128;   // groups of 128 gate rows (one 32-row tile per wave)
@@ -343,13 +347,13 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
     const int chunk = b % n_chunks; b /= n_chunks;
     const int mg = b % MG, d = b / MG;
     const int ld = l * dirs + d;
-    const int I = y.I[l], NCOL = H + I + 1, NTN = (NCOL + 31) / 32;
+    const int I = y.I[l];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
     const bool masked = p.mk.mode != SNN_MASK_NONE;
     const int64_t ts = tape_step_floats(H);
-    f32x16 acc[NTN_MAX];
+    f32x16 acc[NTN];
 #pragma unroll
-    for (int nt = 0; nt < NTN_MAX; ++nt)
+    for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
 
@@ -357,15 +361,15 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
     const int64_t p0 = chunk * per, p1 = std::min<int64_t>(total, p0 + per);
     // Software pipeline over the chunk's tile-steps: the operands of the next tile-step are fetched into registers
     // while the MFMAs of the current one run from LDS (an un-overlapped fetch was ~60 % of the kernel's time).
-    f32x4 gv[4], xv[NTN_MAX];   // 128 dG rows and NTN * 32 [h_prev | x_t | 1 | 0] rows, 8 float4 per row, 256 threads
-    auto next_valid = [&](int64_t pp) {   // first tile-step >= pp inside its tile's length (p1 if none)
+    f32x4 gv[4], xv[NTN];   // 128 dG rows and NTN * 32 [h_prev | x_t | 1 | 0] rows, 8 float4 per row, 256 threads
+    auto next_valid = [&](int64_t pp) __attribute__((always_inline)) {   // first tile-step >= pp inside its tile's length (p1 if none)
         for (; pp < p1; ++pp) {
             const int tile = (int)(pp / p.max_T), t = (int)(pp - (int64_t)tile * p.max_T);
             if (t < p.tile_T[tile]) break;
         }
         return pp;
     };
-    auto fetch = [&](int64_t pp) {
+    auto fetch = [&](int64_t pp) __attribute__((always_inline)) {
         const int tile = (int)(pp / p.max_T), t = (int)(pp - (int64_t)tile * p.max_T);
         const int T = p.tile_T[tile];
         const float* tape = p.tape + (int64_t)tile * p.tape_tile;
@@ -379,42 +383,40 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
         const bool first = d == 0 ? t == 0 : t == T - 1;   // first processed step of this direction: h_prev = 0
         const float* xtile = p.xp + p.tile_off[tile];
 #pragma unroll
-        for (int i = 0; i < NTN_MAX; ++i) {
+        for (int i = 0; i < NTN; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (i < NTN) {
-                if (row < H) {
-                    if (!first) v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32 + row * 32 + c4);
-                } else if (row < H + I) {
-                    const int k = row - H;
-                    if (l == 0) {
-                        v = *reinterpret_cast<const f32x4*>(xtile + ((int64_t)t * y.Dp + k) * 32 + c4);
-                        if (masked) {
+            if (row < H) {
+                if (!first) v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32 + row * 32 + c4);
+            } else if (row < H + I) {
+                const int k = row - H;
+                if (l == 0) {
+                    v = *reinterpret_cast<const f32x4*>(xtile + ((int64_t)t * y.Dp + k) * 32 + c4);
+                    if (masked) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int o = p.order[tile * SNN_TILE + c4 + e];
-                                if (o >= 0) v[e] = __fmul_rn(mask_in(p.mk, 0, p.n_curves, y.D, o, k), v[e]);
-                            }
-                        }
-                    } else {
-                        const int dd = k / H, kk = k - dd * H;
-                        v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)((l - 1) * dirs + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + c4);
-                        if (masked) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int o = p.order[tile * SNN_TILE + c4 + e];
-                                if (o >= 0) v[e] = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = p.order[tile * SNN_TILE + c4 + e];
+                            if (o >= 0) v[e] = __fmul_rn(mask_in(p.mk, 0, p.n_curves, y.D, o, k), v[e]);
                         }
                     }
-                } else if (row == H + I) {
-                    v = f32x4{1.f, 1.f, 1.f, 1.f};
+                } else {
+                    const int dd = k / H, kk = k - dd * H;
+                    v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)((l - 1) * dirs + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + c4);
+                    if (masked) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int o = p.order[tile * SNN_TILE + c4 + e];
+                            if (o >= 0) v[e] = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
+                        }
+                    }
                 }
+            } else if (row == H + I) {
+                v = f32x4{1.f, 1.f, 1.f, 1.f};
             }
             xv[i] = v;
         }
     };
-    auto commit = [&]() {
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
@@ -422,12 +424,10 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
             for (int e = 0; e < 4; ++e) dGs[row * PAD + c4 + e] = gv[i][e];
         }
 #pragma unroll
-        for (int i = 0; i < NTN_MAX; ++i) {
+        for (int i = 0; i < NTN; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
-            if (i < NTN) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = xv[i][e];
-            }
+            for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = xv[i][e];
         }
     };
     int64_t pp = next_valid(p0);
@@ -443,8 +443,8 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
         for (int kk = 0; kk < 16; ++kk) {
             const float a = dGs[(32 * w + cl) * PAD + 2 * kk + hf];
 #pragma unroll
-            for (int nt = 0; nt < NTN_MAX; ++nt)
-                if (nt < NTN) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhs[(32 * nt + cl) * PAD + 2 * kk + hf], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTN; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhs[(32 * nt + cl) * PAD + 2 * kk + hf], acc[nt], 0, 0, 0);
         }
         __syncthreads();
         if (np < p1) commit();
@@ -452,30 +452,53 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
         pp = np;
     }
 
+    // this lane's 16 gate rows: image row -> canonical row of the hidden-side (w_hh, b_hh) / input-side (w_ih, b_ih)
+    // tensors; -1: no such row (GRU: group 2 is the input part of n, group 3 its hidden part; RNN: group 0 only)
     float* slab = p.slabs + (int64_t)chunk * y.P;
+    int Rh[16], Ri[16];
+    float mh[16];
 #pragma unroll
-    for (int nt = 0; nt < NTN_MAX; ++nt) {   // (no early exit: acc[] must stay in registers, i.e. constant-indexed)
-        const int col = nt < NTN ? 32 * nt + cl : H + I + 1;
+    for (int i = 0; i < 16; ++i) {
+        const int R = 128 * mg + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
+        const int grp = R / H, jr = R - grp * H;
+        Rh[i] = y.cell == 0 ? R : y.cell == 1 ? (grp == 2 ? -1 : (grp == 3 ? 2 : grp) * H + jr) : (grp == 0 ? jr : -1);
+        Ri[i] = y.cell == 0 ? R : y.cell == 1 ? (grp == 3 ? -1 : R) : (grp == 0 ? jr : -1);
+        mh[i] = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
+    }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int R = 128 * mg + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            const float v = acc[nt][i];
-            // image row -> canonical row of the hidden-side (w_hh, b_hh) / input-side (w_ih, b_ih) tensors; -1: no such row
-            // (GRU: group 2 is the input part of n, group 3 its hidden part; RNN: group 0 only)
-            const int grp = R / H, jr = R - grp * H;
-            const int Rh = y.cell == 0 ? R : y.cell == 1 ? (grp == 2 ? -1 : (grp == 3 ? 2 : grp) * H + jr) : (grp == 0 ? jr : -1);
-            const int Ri = y.cell == 0 ? R : y.cell == 1 ? (grp == 3 ? -1 : R) : (grp == 0 ? jr : -1);
-            if (col < H) {
-                const float m = (d == 0 && masked) ? mask_whh(p.mk, 0, y.L, H, l, R) : 1.0f;   // gradient of weight_hh_l0_raw
-                if (Rh >= 0) slab[y.c_whh[ld] + (int64_t)Rh * H + col] = m * v;
-            } else if (col - H < I) {
-                if (Ri >= 0) slab[y.c_wih[ld] + (int64_t)Ri * I + (col - H)] = v;
-            } else if (col == H + I) {
-                if (Ri >= 0) slab[y.c_bih[ld] + Ri] = v;
-                if (Rh >= 0) slab[y.c_bhh[ld] + Rh] = v;
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int col = 32 * nt + cl;
+        if (col < H) {
+            float* dst = slab + y.c_whh[ld] + col;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (Rh[i] >= 0) dst[(int64_t)Rh[i] * H] = mh[i] * acc[nt][i];
+        } else if (col - H < I) {
+            float* dst = slab + y.c_wih[ld] + (col - H);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (Ri[i] >= 0) dst[(int64_t)Ri[i] * I] = acc[nt][i];
+        } else if (col == H + I) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (Ri[i] >= 0) slab[y.c_bih[ld] + Ri[i]] = acc[nt][i];
+                if (Rh[i] >= 0) slab[y.c_bhh[ld] + Rh[i]] = acc[nt][i];
             }
         }
     }
+}
+
+// one instantiation per column-tile count that occurs for the hidden size (layer 0: D <= 78; layer >= 1: I = H or 2H)
+typedef void (*bwd_dw_t)(const Bwd2Params, int, int);
+template <int H>
+static bwd_dw_t dw_kernel(int ntn)
+{
+    switch (ntn) {
+#define SNN_DW(N) case N: if constexpr (32 * (N) >= H + 2 && 32 * ((N) - 1) < H + 2 * H + 1) return bwd_dw_kernel<H, N>; else return nullptr;
+        SNN_DW(2) SNN_DW(3) SNN_DW(4) SNN_DW(5) SNN_DW(6) SNN_DW(7) SNN_DW(8) SNN_DW(9) SNN_DW(10) SNN_DW(11) SNN_DW(12) SNN_DW(13)
+#undef SNN_DW
+    }
+    return nullptr;
 }
 
 // dflat[i] (+)= sum over chunks, fixed order; LSTM parameters only (the head is written by head_dw_kernel)
@@ -684,7 +707,6 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);
     HIP_CHECK(hipFuncSetAttribute((const void*)bwd_rec_kernel<H, CELL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec));
-    constexpr int NTN_MAX = (H + 2 * H + 1 + 31) / 32;   // widest layer: I = 2H (or D <= 78 <= 2H for H >= 64)
     float* dyA = p.dfeat + g.dfeat_floats + g.dG_floats;
     float* dyB = dyA + g.dy_floats;
     for (int l = y.L - 1; l >= 0; --l) {
@@ -700,9 +722,11 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
             HIP_CHECK(hipGetLastError());
         }
         const int ntn = (H + y.I[l] + 1 + 31) / 32;
+        bwd_dw_t dw = dw_kernel<H>(ntn);
+        if (!dw) { snn_set_error("no weight-gradient kernel for H=%d with input width %d", H, y.I[l]); return SNN_ERR_UNSUPPORTED; }
         const size_t lds_dw = sizeof(float) * ((size_t)128 * PAD + (size_t)ntn * 32 * PAD);
-        HIP_CHECK(hipFuncSetAttribute((const void*)bwd_dw_kernel<H, NTN_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-        hipLaunchKernelGGL((bwd_dw_kernel<H, NTN_MAX>), dim3(y.dirs * (4 * H / 128) * g.n_chunks), dim3(256), lds_dw, st, p, l, g.n_chunks);
+        HIP_CHECK(hipFuncSetAttribute((const void*)dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
+        hipLaunchKernelGGL(dw, dim3(y.dirs * (4 * H / 128) * g.n_chunks), dim3(256), lds_dw, st, p, l, g.n_chunks);
         HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y.c_head_w, y.P,

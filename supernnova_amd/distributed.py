@@ -94,8 +94,13 @@ def shard_range(n, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
-def allreduce_mean_scale(flat, group=None, producer_stream=None):
-    """Sum-all-reduce `flat` in place (one call) and return the factor that turns the sum into the mean.
+def allreduce_mean_scale(flat, group=None, producer_stream=None, mean=True):
+    """Sum-all-reduce `flat` in place (one call) and return the factor that turns the sum into the mean (1.0 with
+    mean=False: the caller has already weighted its contribution, see _HipRNN.fused_train_step).
+
+    The MEAN of per-rank gradients equals the single-process gradient only for EQUAL shards (each rank's CE is a mean
+    over its own curves): train_step refuses unequal shards; the fused step weights every curve by 1 / global batch
+    and every rank's (identical) KL gradient by 1 / world instead, sums, and is exact for any split.
 
     Ordering: the kernels of this package are launched on torch's CURRENT stream (engine._stream), and
     torch.distributed's all_reduce orders itself against the current stream on both sides (RCCL: its internal stream
@@ -122,7 +127,7 @@ def allreduce_mean_scale(flat, group=None, producer_stream=None):
             flat.copy_(h)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    return 1.0 / w
+    return 1.0 / w if mean else 1.0
 
 
 def broadcast_parameters(model, src=0, group=None):

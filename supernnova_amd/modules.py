@@ -236,9 +236,12 @@ class _HipRNN(nn.Module):
         self.flat_parameters()
         return _TrainFn.apply(self, padded, lengths, masks_fn, eps, mean_field_inference, *self._flat_params())
 
-    def fused_train_step(self, x, target, optimizer, kl_scale=0.0, eps=None, masks=None):
+    def fused_train_step(self, x, target, optimizer, kl_scale=0.0, eps=None, masks=None, global_batch=None):
         """One training step without autograd (utils/training_utils.py:508-525 in five launches):
-        forward-train, CE + dlogits, BPTT, (BBB backward), fused Adam.  Returns the loss (device scalar)."""
+        forward-train, CE + dlogits, BPTT, (BBB backward), fused Adam.  Returns the loss (device scalar).
+        Data parallel (torch.distributed initialised, `global_batch` = curves of ALL ranks in this step): every curve's
+        CE gradient is weighted 1 / global_batch and the rank-identical KL gradient 1 / world, and the ranks' flat
+        gradients are SUMMED -- the single-process gradient for any split of the batch, equal shards or not."""
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
@@ -272,21 +275,26 @@ class _HipRNN(nn.Module):
         mark("sample")
         logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, masks)
         mark("forward")
-        ce, dlogits = E.ce_loss_grad(logits, target)
+        from .distributed import world_size
+        world = world_size(getattr(optimizer, "process_group", None))
+        dp = world > 1 and global_batch is not None
+        if dp and not (plan.n_curves <= global_batch):
+            raise ValueError(f"fused_train_step: this rank holds {plan.n_curves} curves but global_batch is {global_batch}")
+        ce, dlogits = E.ce_loss_grad(logits, target, grad_scale=1.0 / global_batch if dp else None)
         mark("ce")
         dw = E.lstm_backward(cfg, plan, xp, wk, tape, dlogits, masks)
         mark("backward")
         if bayes:
             P, Ps = cfg.P, cfg.P - cfg.nb_classes
             gflat = torch.empty(P + Ps, dtype=torch.float32, device=dev)
-            E.bbb_backward(cfg, mu, rho, self._prior, terms, dw, mode, eps=eps, seed=seed, kl_scale=kl_scale,
-                           dmu=gflat[:P], drho=gflat[P:])
+            E.bbb_backward(cfg, mu, rho, self._prior, terms, dw, mode, eps=eps, seed=seed,
+                           kl_scale=kl_scale / world if dp else kl_scale, dmu=gflat[:P], drho=gflat[P:])
             self.kl = kl
             loss = ce + kl * kl_scale
         else:
             gflat, loss = dw, ce
         mark("bbb_backward")
-        optimizer.step_flat(gflat)
+        optimizer.step_flat(gflat, mean=not dp)
         mark("allreduce+adam")
         self.last_logits = logits
         return loss

@@ -48,14 +48,16 @@ class _FlatOptimizer:
     def step(self):
         self.step_flat(self._flat_grads())
 
-    def step_flat(self, grads):
-        """Update from a gradient already laid out like model.flat_parameters()."""
+    def step_flat(self, grads, mean=True):
+        """Update from a gradient already laid out like model.flat_parameters().  Under torch.distributed the ranks'
+        gradients are summed by ONE all-reduce and, with mean=True, divided by the world size (exact for equal shards);
+        mean=False takes the plain sum of contributions the caller has weighted itself (fused_train_step: any split)."""
         from .distributed import allreduce_mean_scale
         flat = self.model.flat_parameters()
         if grads.numel() != flat.numel():
             raise RuntimeError(f"{type(self).__name__}: flat gradient size does not match the parameters")
         # ONE all-reduce of the whole gradient (160-320 KB at H=32): latency-bound over xGMI, so a single call
-        scale = allreduce_mean_scale(grads, self.process_group)
+        scale = allreduce_mean_scale(grads, self.process_group, mean=mean)
         st = self.state
         for k in self._buffers:
             if st[k] is None or st[k].numel() != flat.numel() or st[k].device != flat.device:

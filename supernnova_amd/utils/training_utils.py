@@ -47,6 +47,13 @@ def train_step(settings, rnn, packed_tensor, target_tensor, criterion, optimizer
     forward, CE (+ KL/(num_batches*batch_size) for BayesianRNN), backward, optimizer step.
     Under torch.distributed each rank passes its shard of the mini-batch and batch_size = the GLOBAL batch
     size; the optimizer all-reduces (averages) the flat gradient."""
+    from ..distributed import world_size
+    world = world_size(getattr(optimizer, "process_group", None))
+    if world > 1 and int(target_tensor.size(0)) * world != int(batch_size):
+        # the optimizer averages the ranks' gradients, each a mean over that rank's own curves: with unequal shards
+        # that is not the gradient of the global mini-batch.  train_step_fused weights curves exactly for any split.
+        raise ValueError(f"train_step under torch.distributed needs equal shards (this rank: {int(target_tensor.size(0))} "
+                         f"curves, world {world}, global batch {int(batch_size)}): use train_step_fused, or pad the shards")
     rnn.train()
     optimizer.zero_grad()
     output = rnn(packed_tensor)
@@ -63,7 +70,8 @@ def train_step_fused(settings, rnn, packed_tensor, target_tensor, optimizer, bat
     KL scale known on the host, one Adam launch.  Returns the loss as a device scalar."""
     from .. import engine as E
     rnn.train()
-    return rnn.fused_train_step(packed_tensor, target_tensor, optimizer, 1.0 / (num_batches * batch_size))
+    return rnn.fused_train_step(packed_tensor, target_tensor, optimizer, 1.0 / (num_batches * batch_size),
+                                global_batch=batch_size)
 
 
 def unnormalize_arr(arr, settings):

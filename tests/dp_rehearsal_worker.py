@@ -36,6 +36,9 @@ def run(model, steps, rank, world, dev, process_group_ready):
     x, lengths, target = batch()
     B = len(lengths)
     s, e = D.shard_range(B, rank, world)
+    if world == 2 and os.environ.get("SNN_DP_SPLIT"):       # unequal shards: [0, split) and [split, B)
+        cut = int(os.environ["SNN_DP_SPLIT"])
+        s, e = (0, cut) if rank == 0 else (cut, B)
     pk = pack_padded_sequence(torch.from_numpy(x[:int(lengths[s]), s:e]).to(dev), torch.from_numpy(lengths[s:e].astype(np.int64)))
     tg = torch.from_numpy(target[s:e]).to(dev)
     losses = []
@@ -43,7 +46,7 @@ def run(model, steps, rank, world, dev, process_group_ready):
         faulthandler.dump_traceback_later(60, exit=True)     # inactivity limit per step
         losses.append(float(tu.train_step_fused(st, rnn, pk, tg, opt, B, 100)))
     faulthandler.cancel_dump_traceback_later()
-    return rnn.flat_parameters().detach().cpu().numpy(), np.array(losses)
+    return rnn.flat_parameters().detach().cpu().numpy(), np.array(losses), e - s
 
 
 def main():
@@ -53,7 +56,7 @@ def main():
     dev = torch.device("cuda", 0)
     from supernnova_amd import distributed as D
     D.init_from_env("gloo")
-    flat, losses = run(model, steps, rank, world, dev, True)
+    flat, losses, n_local = run(model, steps, rank, world, dev, True)
     # inference exchange: every rank contributes a (n_local, 4) block of "predictions"
     n = 37
     s, e = D.shard_range(n, rank, world)
@@ -61,7 +64,7 @@ def main():
     full = D.gather_predictions(local, n, dst=0)
     if rank == 0:
         assert full.is_cuda and torch.equal(full[:, 0].cpu(), torch.arange(n, dtype=torch.float32))
-    np.savez(f"{out}.rank{rank}.npz", flat=flat, losses=losses)
+    np.savez(f"{out}.rank{rank}.npz", flat=flat, losses=losses, n_local=n_local)
     torch.distributed.destroy_process_group()
 
 

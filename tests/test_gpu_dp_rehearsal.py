@@ -13,27 +13,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("model", ["bayesian"])
-def test_two_ranks_on_one_gpu_match_single_process(model, tmp_path):
+@pytest.mark.parametrize("model,split", [("bayesian", None), ("bayesian", 59), ("variational", 7)])
+def test_two_ranks_on_one_gpu_match_single_process(model, split, tmp_path):
+    """split None: equal halves of the 96-curve batch; otherwise rank 0 takes the first `split` curves and rank 1 the
+    rest -- the fused step weights every curve 1 / global batch and the KL gradient 1 / world, so ANY split gives the
+    single-process step (averaging per-rank means is biased for unequal shards)."""
     from supernnova_amd.distributed import self_launch
     import dp_rehearsal_worker as W
     out = str(tmp_path / "dp")
-    env_before = os.environ.get("SNN_BENCH_BACKEND")
+    keep = {k: os.environ.get(k) for k in ("SNN_BENCH_BACKEND", "SNN_DP_SPLIT")}
     os.environ["SNN_BENCH_BACKEND"] = "gloo"          # self_launch: ranks may share a device
+    if split is not None:
+        os.environ["SNN_DP_SPLIT"] = str(split)
     try:
         rc = self_launch(os.path.join(ROOT, "tests", "dp_rehearsal_worker.py"), [model, "3", out], 2, timeout=240)
     finally:
-        if env_before is None:
-            os.environ.pop("SNN_BENCH_BACKEND")
-        else:
-            os.environ["SNN_BENCH_BACKEND"] = env_before
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     assert rc == 0, f"2-rank rehearsal exited with {rc}"
     r0, r1 = (np.load(f"{out}.rank{r}.npz") for r in range(2))
     assert np.array_equal(r0["flat"], r1["flat"]), "ranks diverged (Adam runs redundantly on identical reduced gradients)"
-    ref, ref_losses = W.run(model, 3, 0, 1, torch.device("cuda", 0), False)
+    assert int(r0["n_local"]) + int(r1["n_local"]) == 96 and (split is None or int(r0["n_local"]) == split)
+    ref, ref_losses, _ = W.run(model, 3, 0, 1, torch.device("cuda", 0), False)
     # half-batch gradients averaged vs full-batch gradient: equal to summation rounding (2e-6 of max |grad|, see
     # test_data_parallel_gradient_equals_full_batch_gradient); Adam's normalised update turns that into at most a few
     # 1e-7 per step on the parameters
     assert float(np.abs(r0["flat"] - ref).max()) < 5e-6
-    # each rank reports CE of its own half + the shared KL term; their mean is the full-batch loss
-    np.testing.assert_allclose(0.5 * (r0["losses"] + r1["losses"]), ref_losses, rtol=2e-6)
+    # each rank reports the mean CE of its own shard + the shared KL term; weighted by shard size they give the full-batch loss
+    w0 = int(r0["n_local"]) / 96.0
+    np.testing.assert_allclose(w0 * r0["losses"] + (1 - w0) * r1["losses"], ref_losses, rtol=2e-6)

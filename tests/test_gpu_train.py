@@ -358,7 +358,7 @@ def test_data_parallel_gradient_equals_full_batch_gradient(model):
     eps = rnn.host_eps(1, DEV) if model == "bayesian" else None
 
     class Rec:
-        def step_flat(self, grads):
+        def step_flat(self, grads, mean=True):
             self.g = grads.detach().clone()
 
     def grads(s, e):
@@ -562,3 +562,92 @@ def test_layerwise_and_persistent_training_forward_write_the_same_tape(masked):
     assert torch.equal(torch.where(live, rows_a, 0.0), torch.where(live, rows_b, 0.0))
     assert torch.equal(ta[:, 4 * plan.max_T * step:], tb[:, 4 * plan.max_T * step:])          # pooled features
     assert torch.equal(res[0][2], res[1][2])
+
+
+def _forward_train_variants(cfg, n, T, masks_fn, seed=5, variants=("0", "1")):
+    """(logits, tape, dflat) of the training forward + backward with SNN_FWD_SPLIT forced to each of `variants`
+    ("0": one kernel per layer / persistent kernel; "1": fwd_gx_kernel + recurrent kernel), same inputs."""
+    import os
+    from supernnova_amd import engine as E
+    from util import make_curves
+    x, lengths = make_curves(seed + 18, n, T, cfg.input_size, min_len=1)
+    w = np.random.default_rng(seed).uniform(-0.3, 0.3, cfg.P).astype(np.float32)
+    wk = E.prepare_weights(cfg, _t(w))
+    plan = E.Plan(cfg, lengths, DEV)
+    xp = E.pack_x(cfg, plan, _t(x))
+    dlog = torch.linspace(-1, 1, n * cfg.nb_classes, device=DEV).view(n, cfg.nb_classes)
+    res, names = [], []
+    for v in variants:
+        os.environ["SNN_FWD_SPLIT"] = v
+        try:
+            logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, masks_fn(plan))
+            names.append(E.last_forward_kernel())
+            dflat = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, masks_fn(plan))
+        finally:
+            os.environ.pop("SNN_FWD_SPLIT", None)
+        res.append((logits, tape.clone(), dflat))
+    return plan, res, names
+
+
+def _assert_same_tape(cfg, plan, a, b):
+    H, n_ld = cfg.hidden_size, cfg.num_layers * cfg.dirs
+    assert torch.equal(a[0], b[0])                                     # logits
+    step = 6 * H * 32
+    per_tile = n_ld * plan.max_T * step + cfg.F * 32
+    ta = a[1][: plan.n_tiles * per_tile].view(plan.n_tiles, per_tile)
+    tb = b[1][: plan.n_tiles * per_tile].view(plan.n_tiles, per_tile)
+    tile_T = torch.from_numpy(np.array(plan.tile_T, dtype=np.int64)).to(DEV)
+    rows_a = ta[:, : n_ld * plan.max_T * step].view(plan.n_tiles, n_ld, plan.max_T, step)
+    rows_b = tb[:, : n_ld * plan.max_T * step].view(plan.n_tiles, n_ld, plan.max_T, step)
+    live = (torch.arange(plan.max_T, device=DEV)[None, :] < tile_T[:, None])[:, None, :, None]
+    assert torch.equal(torch.where(live, rows_a, 0.0), torch.where(live, rows_b, 0.0))   # every row the backward reads
+    assert torch.equal(ta[:, n_ld * plan.max_T * step:], tb[:, n_ld * plan.max_T * step:])   # pooled features
+    assert torch.equal(a[2], b[2])                                     # gradients
+
+
+@pytest.mark.parametrize("D,H,L,bidir,pool,C,cell,masked,n,T", [
+    (24, 32, 2, True, "mean", 2, "lstm", None, 128, 40),          # the reference's batch (conf.py:517)
+    (24, 32, 2, True, "mean", 2, "lstm", "locked", 100, 17),      # VariationalRNN masks
+    (26, 32, 3, True, "standard", 3, "lstm", "step", 70, 9),      # per-step between-layer dropout (VanillaRNN, train mode)
+    (24, 32, 2, False, "standard", 2, "lstm", None, 33, 12),      # unidirectional: no layer-wise kernel, persistent one
+    (42, 64, 2, True, "mean", 5, "lstm", "locked", 65, 11),
+    (24, 32, 2, True, "mean", 2, "gru", None, 64, 13),
+    (24, 64, 1, True, "standard", 3, "rnn", None, 40, 8),
+    (78, 128, 2, True, "mean", 14, "lstm", None, 40, 21),         # configs[4] shape, H = 128 kernels
+    (24, 128, 2, True, "standard", 2, "lstm", "locked", 33, 7),
+    (24, 32, 2, True, "mean", 2, "lstm", None, 1, 1),             # one curve, one step
+])
+def test_split_training_forward_is_bit_identical(D, H, L, bidir, pool, C, cell, masked, n, T):
+    """Small batches run the training forward as fwd_gx_kernel (input products of a whole layer, one launch over the
+    chip) + a recurrent kernel per (tile, direction) whose steps issue only the H / 2 recurrent MFMAs.  Same products in
+    the same order as the one-kernel forms: logits, every live tape row, pooled features and the gradients computed from
+    the tape are bit-identical."""
+    from supernnova_amd import engine as E
+    cfg = E.Config(D, H, L, bidir, C, pool, cell=cell)
+
+    def masks_fn(plan):
+        if masked == "locked":
+            return E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=78, mid_T=1)
+        if masked == "step":
+            return E.Masks(mode=2, which=4 | 8, dropout=0.2, seed=79, mid_T=plan.max_T)
+        return None
+    plan, res, names = _forward_train_variants(cfg, n, T, masks_fn)
+    assert "fwd_gx_kernel" in names[1] and "fwd_gx_kernel" not in names[0], names
+    _assert_same_tape(cfg, plan, res[0], res[1])
+
+
+def test_small_batches_take_the_split_forward_by_default():
+    """Dispatch: while every (tile, direction) gets a compute unit of its own the split forward is chosen; beyond that
+    the one-kernel-per-layer form.  Results do not depend on which one ran (above)."""
+    import os
+    from supernnova_amd import engine as E
+    assert "SNN_FWD_SPLIT" not in os.environ
+    cfg = E.Config(24, 32, 2, True, 2, "mean")
+    from util import make_curves
+    for n, want in ((128, True), (32 * 1024, False)):
+        x, lengths = make_curves(3, n, 12, 24, min_len=1)
+        plan = E.Plan(cfg, lengths, DEV)
+        xp = E.pack_x(cfg, plan, _t(x))
+        wk = E.prepare_weights(cfg, torch.zeros(cfg.P, device=DEV))
+        E.lstm_forward_train(cfg, plan, xp, wk, None)
+        assert ("fwd_gx_kernel" in E.last_forward_kernel()) == want, E.last_forward_kernel()
