@@ -395,6 +395,53 @@ int snn_adam_step(int64_t n, float *params, const float *grads, float *exp_avg, 
 int snn_sgd_step(int64_t n, float *params, const float *grads, float *momentum_buf, int64_t step, float lr,
                  float momentum, float weight_decay, float grad_scale, void *stream);
 
+/*
+ * One training step up to the flat gradient, as ONE call: the reference's
+ *     rnn.train(); optimizer.zero_grad(); output = rnn(packed_tensor); loss = criterion(output.squeeze(), target_tensor)
+ *     [+ rnn.kl / (num_batches * batch_size)]; loss.backward()                    utils/training_utils.py:508-523
+ * i.e. snn_pack_x_steps (or snn_pack_x), snn_bbb_sample (BayesianRNN) or snn_prepare_weights, snn_lstm_forward_train,
+ * snn_ce_loss_grad, snn_lstm_backward and snn_bbb_backward enqueued back to back on `stream` -- the same launches in the
+ * same order as the separate entry points (results are identical), without a host round trip per launch: at the
+ * reference's batch size (128, conf.py:517) the step is a few hundred microseconds of GPU work and the host side of
+ * twelve separate calls took longer than that.  The optimizer step stays separate (snn_adam_step / snn_sgd_step): under
+ * data parallelism the all-reduce of `grad` sits between the two.  All buffers are the caller's:
+ *   x, step_off, stride_n, curve_off   the batch as snn_pack_x_steps takes it (step_off != NULL), or as snn_pack_x takes it
+ *                                      (step_off == NULL: stride_t is used)
+ *   order .. tile_off, n_curves, n_tiles, max_T, xp_floats     device copy of the snn_plan_build plan
+ *   target (n_curves) int64
+ *   params   canonical flat parameters: P floats (VanillaRNN / VariationalRNN), or mu (P) when rho != NULL
+ *   rho      NULL, or rho (P - C): Bayes-by-Backprop draw with eps / bbb_mode / seed / offset / prior as snn_bbb_sample
+ *   masks    NULL or the dropout masks of forward and backward
+ *   ce_grad_scale   dlogits = ce_grad_scale * (softmax - onehot): 1 / n_curves, or 1 / global batch under data parallelism
+ *   kl_scale        weight of the KL gradient (1 / (num_batches * batch_size), divided by the world size under DP)
+ *   loss_kl_scale   weight of the KL term in the reported loss (1 / (num_batches * batch_size))
+ *   out: xp (xp_floats), wk (PK), kl (1) + kl_terms ((4 L dirs + 1) * 3) [Bayesian], logits (n_curves, C), tape
+ *        (snn_train_tape_floats), dlogits (n_curves, C), loss (2 floats: mean CE of this batch, and for BayesianRNN
+ *        CE + loss_kl_scale * KL), ce_partials (snn_ce_loss_partials doubles, may be NULL for n <= 1024), dw (P: the
+ *        gradient w.r.t. the weight set -- for VanillaRNN / VariationalRNN THE gradient), grad (BayesianRNN only:
+ *        P + P - C floats, dmu then drho), fwd_ws / bwd_ws as the separate entry points size them.
+ */
+typedef struct snn_train_io {
+    const float *x; const int64_t *step_off; int64_t stride_t, stride_n; const int64_t *curve_off;
+    const int32_t *order, *len_sorted, *tile_T; const int64_t *tile_off;
+    int32_t n_curves, n_tiles, max_T, bbb_mode;
+    int64_t xp_floats;
+    const int64_t *target;
+    const float *params, *rho, *eps;
+    uint64_t seed, offset;
+    const snn_prior *prior;
+    const snn_masks *masks;
+    float ce_grad_scale, kl_scale, loss_kl_scale, reserved;
+    float *xp, *wk, *kl, *kl_terms, *logits, *tape;
+    int64_t tape_floats;
+    float *dlogits, *loss;
+    double *ce_partials;
+    float *dw, *grad;
+    void *fwd_ws; int64_t fwd_ws_bytes;
+    void *bwd_ws; int64_t bwd_ws_bytes;
+} snn_train_io;
+int snn_train_step_grad(const snn_cfg *cfg, const snn_train_io *io, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,27 @@ class SnnMasks(ctypes.Structure):
                 ("m_mid", ctypes.c_void_p), ("m_out", ctypes.c_void_p)]
 
 
+class SnnTrainIO(ctypes.Structure):
+    """snn_train_io of include/snn_hip.h (snn_train_step_grad)."""
+    _fields_ = [("x", ctypes.c_void_p), ("step_off", ctypes.c_void_p), ("stride_t", ctypes.c_int64), ("stride_n", ctypes.c_int64),
+                ("curve_off", ctypes.c_void_p),
+                ("order", ctypes.c_void_p), ("len_sorted", ctypes.c_void_p), ("tile_T", ctypes.c_void_p), ("tile_off", ctypes.c_void_p),
+                ("n_curves", ctypes.c_int32), ("n_tiles", ctypes.c_int32), ("max_T", ctypes.c_int32), ("bbb_mode", ctypes.c_int32),
+                ("xp_floats", ctypes.c_int64),
+                ("target", ctypes.c_void_p),
+                ("params", ctypes.c_void_p), ("rho", ctypes.c_void_p), ("eps", ctypes.c_void_p),
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+                ("prior", ctypes.POINTER(SnnPrior)), ("masks", ctypes.POINTER(SnnMasks)),
+                ("ce_grad_scale", ctypes.c_float), ("kl_scale", ctypes.c_float), ("loss_kl_scale", ctypes.c_float),
+                ("reserved", ctypes.c_float),
+                ("xp", ctypes.c_void_p), ("wk", ctypes.c_void_p), ("kl", ctypes.c_void_p), ("kl_terms", ctypes.c_void_p),
+                ("logits", ctypes.c_void_p), ("tape", ctypes.c_void_p), ("tape_floats", ctypes.c_int64),
+                ("dlogits", ctypes.c_void_p), ("loss", ctypes.c_void_p), ("ce_partials", ctypes.c_void_p),
+                ("dw", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+                ("fwd_ws", ctypes.c_void_p), ("fwd_ws_bytes", ctypes.c_int64),
+                ("bwd_ws", ctypes.c_void_p), ("bwd_ws_bytes", ctypes.c_int64)]
+
+
 class SnnError(RuntimeError):
     pass
 
@@ -93,6 +114,7 @@ SIGNATURES = {
     "snn_ce_loss_partials": (ctypes.c_int64, [ctypes.c_int32]),
     "snn_ce_loss_grad": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _P, _P, ctypes.c_float, _P, _P, _P, _P]),
     "snn_adam_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 6 + [_P]),
+    "snn_train_step_grad": (ctypes.c_int, [_CFG, ctypes.POINTER(SnnTrainIO), _P]),
     "snn_sgd_step": (ctypes.c_int, [ctypes.c_int64, _P, _P, _P, ctypes.c_int64] + [ctypes.c_float] * 4 + [_P]),
 }
 

@@ -132,6 +132,19 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
     return s;
 }
 
+// the three log-probability sums of compute_KL in one pass: same shuffle tree and the same wave order as block_sum
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (int)(blockDim.x >> 6);
+    if (lane == 0) { sh[w] = a; sh[16 + w] = b; sh[32 + w] = c; }
+    __syncthreads();
+    double sa = 0, sb = 0, sc = 0;
+    for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[16 + i]; sc += sh[32 + i]; }
+    a = sa; b = sb; c = sc;
+}
+
 __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
                                                         const float* __restrict__ rho,
                                                         const float* __restrict__ eps, int mode,
@@ -139,7 +152,7 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
                                                         float* __restrict__ wk, float* __restrict__ kl_terms,
                                                         int64_t mu_stride)
 {
-    __shared__ double sh[16];
+    __shared__ double sh[48];
     const int tau = blockIdx.x, s = blockIdx.y;
     mu += (int64_t)s * mu_stride;   // snn_prepare_weights_multi: one canonical weight set per sample
     const TensorGeom g = tensor_geom(y, tau);
@@ -152,7 +165,7 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
     const float s2 = g.kind == 4 ? prior.sigma2_out : prior.sigma2;
     const float v1 = s1 * s1, v2 = s2 * s2, l1 = logf(s1), l2 = logf(s2);
     double q = 0, p1 = 0, p2 = 0;
-    for (int64_t i = threadIdx.x; i < g.n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (int)g.n; i += blockDim.x) {
         const int64_t p = g.cbase + i;
         const float m = mu[p];
         float w = m;
@@ -192,9 +205,7 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
         }
     }
     if (kl_terms != nullptr && g.kind != 5) {
-        q = block_sum(q, sh);
-        p1 = block_sum(p1, sh);
-        p2 = block_sum(p2, sh);
+        block_sum3(q, p1, p2, sh);
         if (threadIdx.x == 0) {
             float term = 0.0f, r1 = 0.0f, r2 = 0.0f;
             if (sampled) {
@@ -737,7 +748,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
             float* head_part = (float*)((char*)workspace + part_off);
             float* gx = (float*)((char*)workspace + gx_off);
             const size_t lds = e->big ? sizeof(float) * ((size_t)3 * y.H * 32 + (size_t)5 * y.C * 32) + 16
-                                      : sizeof(float) * ((size_t)2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
+                                      : sizeof(float) * ((size_t)2 * SNN_TAPE_Q * y.H * 32 + (size_t)2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
             HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_rec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             snprintf(g_last_kernel, sizeof(g_last_kernel), "fwd_gx_kernel + %s<%d,%d,%d,cell%d> x %d layers grid=%d block=%d lds=%zu",
                      e->big ? "lstm_fwd_big_rec_kernel" : "lstm_fwd_rec_kernel", y.H, y.KKI[0], y.dirs, y.cell, y.L,

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256, KKI > 64 ? 1 : 2) fwd_gx_kernel(const Fwd
                     const float* src;
                     if (FIRST) src = in0 + (int64_t)t * (2 * KKI * 32) + kk * 64 + lane;
                     else {
-                        const int dd = (2 * kk) / H;     // rows 2 kk and 2 kk + 1 lie in the same direction block (H is even)
+                        const int dd = 2 * kk >= H ? 1 : 0;     // (dirs <= 2) rows 2 kk and 2 kk + 1 lie in the same direction block: H is even
                         src = in0 + ((int64_t)dd * p.max_T + t) * ts + (2 * kk - dd * H) * 32 + lane;
                     }
                     bq[k] = *src;
@@ -167,10 +167,10 @@ int snn_launch_gx(const SnnLayout& y, const FwdParams& p, int l, float* gx, int 
     g.H = y.H; g.dirs = y.dirs; g.l = l; g.KK = y.KK[l];
     g.n_rg = (y.H / 8 + 3) / 4;
     for (int d = 0; d < y.dirs; ++d) { g.k_A[d] = y.k_A[l * y.dirs + d]; g.k_bias[d] = y.k_bias[l * y.dirs + d]; }
-    // chunks of steps: enough workgroups for ~2 per compute unit, at least 4 steps per chunk (each workgroup loads its
-    // rows of W_ih once and amortises them over the chunk)
+    // chunks of steps: enough workgroups for ~2 per compute unit, at least 2 steps per chunk (each workgroup loads its
+    // rows of W_ih once and amortises them over the chunk; a chunk's steps are a chain of dependent memory round trips)
     const int64_t base = (int64_t)p.n_tiles * y.dirs * g.n_rg;
-    int n_tchunks = (int)std::max<int64_t>(1, std::min<int64_t>((p.max_T + 3) / 4, (2 * (int64_t)cus + base - 1) / base));
+    int n_tchunks = (int)std::max<int64_t>(1, std::min<int64_t>((p.max_T + 1) / 2, (2 * (int64_t)cus + base - 1) / base));
     g.TC = (p.max_T + n_tchunks - 1) / n_tchunks;
     g.n_tchunks = (p.max_T + g.TC - 1) / g.TC;
     g.gx = gx;

@@ -184,6 +184,17 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];
             }
+            // tape row of the step before: staged in LDS by its cell update (below), written here as 16-byte words --
+            // 6 store instructions per thread beside this step's MFMAs instead of 24 4-byte ones between the cell
+            // update and the barrier (with one workgroup per compute unit nothing else hides their issue time)
+            if (TRAIN && step > 0) {
+                const int tprev = d == 0 ? t - 1 : t + 1;
+                const float* sg = xin + ((step - 1) & 1) * (SNN_TAPE_Q * H * 32);
+                float* dst = tape_ld + (int64_t)tprev * tape_step_floats(H);
+#pragma unroll
+                for (int i = 0; i < SNN_TAPE_Q; ++i)
+                    *reinterpret_cast<f32x4*>(dst + (c.tid + i * NT) * 4) = *reinterpret_cast<const f32x4*>(sg + (c.tid + i * NT) * 4);
+            }
         } else {
             acc = *binit_p;
             const float* xc = xin + cur * XIN_STRIDE + c.lane;
@@ -226,7 +237,16 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             hst[u] = valid ? hv : hst[u];
             outv[u] = valid ? hv : 0.0f;
             hn[u * 32] = hst[u];
-            if (TRAIN) {
+            if (TRAIN && GX) {
+                float* sg = xin + (step & 1) * (SNN_TAPE_Q * H * 32) + (j0 + u) * 32 + c.cl;
+                sg[0 * H * 32] = ig;
+                sg[1 * H * 32] = fg;
+                sg[2 * H * 32] = gg;
+                sg[3 * H * 32] = og;
+                sg[4 * H * 32] = cn;
+                sg[5 * H * 32] = outv[u];
+            }
+            if (TRAIN && !GX) {
 #ifdef SNN_ABL_NOTAPE   // timing ablation only (the backward then reads garbage): what the gate / cell tape stores cost
                 if (p.n_curves < 0)
 #endif
@@ -261,6 +281,14 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         }
         if (!GX && more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
         lds_barrier();
+    }
+    if (GX && TRAIN && T > 0) {      // the last step's tape row (its staging writes are behind the loop's closing barrier)
+        const int tlast = d == 0 ? T - 1 : 0;
+        const float* sg = xin + ((T - 1) & 1) * (SNN_TAPE_Q * H * 32);
+        float* dst = tape_ld + (int64_t)tlast * tape_step_floats(H);
+#pragma unroll
+        for (int i = 0; i < SNN_TAPE_Q; ++i)
+            *reinterpret_cast<f32x4*>(dst + (c.tid + i * NT) * 4) = *reinterpret_cast<const f32x4*>(sg + (c.tid + i * NT) * 4);
     }
 
     // ---- head contribution of this phase
@@ -473,7 +501,8 @@ lstm_fwd_rec_kernel(const FwdParams p, int l, float* __restrict__ head_part, con
     constexpr int BLK0 = NW * (KKI0 + H / 2) * 64 + 2 * NW * 32;
     constexpr int BLK1 = NW * (KKI1 + H / 2) * 64 + 2 * NW * 32;
     const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
-    float* hb = smem;                    // [2][H*32]
+    float* stage = smem;                 // [2][6][H*32] tape rows of the last two steps (run_phase<GX>: its `xin`)
+    float* hb = stage + 2 * SNN_TAPE_Q * H * 32;   // [2][H*32]
     float* part = hb + 2 * H * 32;       // [NW][C][32]
     float* logit = part + NW * y.C * 32; // [C][32]
 
@@ -498,10 +527,10 @@ lstm_fwd_rec_kernel(const FwdParams p, int l, float* __restrict__ head_part, con
     __syncthreads();
     if (l == 0) {
         const int kA = d * BLK0;
-        run_phase<H, KKI0, DIRS, true, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, nullptr, hb, part, logit, nullptr);
+        run_phase<H, KKI0, DIRS, true, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI0 + H / 2) * 64, k_head_w, stage, hb, part, logit, nullptr);
     } else {
         const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-        run_phase<H, KKI1, DIRS, false, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, nullptr, hb, part, logit, nullptr);
+        run_phase<H, KKI1, DIRS, false, true, SNN_LAYER_MASKED, CELL, true>(p, c, l, d, kA, kA + NW * (KKI1 + H / 2) * 64, k_head_w, stage, hb, part, logit, nullptr);
     }
     if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {
         float* dst = head_part + ((int64_t)c.tile * (y.L * DIRS) + l * DIRS + d) * (NW * y.C * 32);

@@ -89,14 +89,14 @@ __device__ __forceinline__ TensorGeom tensor_geom(const SnnLayout& y, int tau)
 }
 
 // canonical element i of tensor g -> index in the kernel layout
-__device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const TensorGeom& g, int64_t i)
+__device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const TensorGeom& g, int i)   // (32-bit: a 64-bit division per element was most of bbb_sample_kernel)
 {
     if (g.kind == 4) return y.k_head_w + i;
     if (g.kind == 5) return y.k_head_b + i;
     const int l = g.ld / y.dirs;
     const int H = y.H;
     if (g.kind <= 1) {
-        const int R = (int)(i / g.cols), col = (int)(i - (int64_t)R * g.cols);
+        const int R = i / g.cols, col = i - R * g.cols;
         const int gate = R / H, j = R - gate * H;
         const int w = j >> 3, r = snn_row_group(y.cell, gate, g.kind == 1) * 8 + (j & 7);
         const int k = g.kind == 0 ? col : 2 * y.KKI[l] + col;
@@ -110,10 +110,10 @@ __device__ __forceinline__ int64_t kernel_index(const SnnLayout& y, const Tensor
 
 // precision 1: index (in bf16 units from the start of the weight set) of piece 0 of canonical element i of a
 // weight matrix g (kind 0 / 1); piece p sits 64 * 8 * p further
-__device__ __forceinline__ int64_t kernel_index3(const SnnLayout& y, const TensorGeom& g, int64_t i)
+__device__ __forceinline__ int64_t kernel_index3(const SnnLayout& y, const TensorGeom& g, int i)
 {
     const int l = g.ld / y.dirs, H = y.H;
-    const int R = (int)(i / g.cols), col = (int)(i - (int64_t)R * g.cols);
+    const int R = i / g.cols, col = i - R * g.cols;
     const int gate = R / H, j = R - gate * H;
     const int w = j >> 3, r = gate * 8 + (j & 7);
     const int k = g.kind == 0 ? col : 16 * y.XB[l] + col;

@@ -271,7 +271,8 @@ extern "C" int snn_bbb_backward(const snn_cfg* cfg, const float* mu, const float
 __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const float* __restrict__ logits,
                                                           const int64_t* __restrict__ target, float scale,
                                                           float* __restrict__ loss, float* __restrict__ dlogits,
-                                                          double* __restrict__ partials)
+                                                          double* __restrict__ partials, const float* __restrict__ kl,
+                                                          float kl_scale)
 {
     __shared__ double sh[4];
     double acc = 0.0;
@@ -295,22 +296,37 @@ __global__ void __launch_bounds__(256) ce_loss_grad_kernel(int N, int C, const f
     __syncthreads();
     if (threadIdx.x == 0) {
         const double part = sh[0] + sh[1] + sh[2] + sh[3];
-        if (gridDim.x == 1) *loss = (float)(part / (double)N);
-        else partials[blockIdx.x] = part;
+        if (gridDim.x == 1) {
+            const float ce = (float)(part / (double)N);
+            loss[0] = ce;
+            if (kl) loss[1] = ce + kl[0] * kl_scale;      // the step's loss, utils/training_utils.py:515-518
+        } else partials[blockIdx.x] = part;
     }
 }
 
-__global__ void ce_loss_sum_kernel(int N, int blocks, const double* __restrict__ partials, float* __restrict__ loss)
+__global__ void ce_loss_sum_kernel(int N, int blocks, const double* __restrict__ partials, float* __restrict__ loss,
+                                   const float* __restrict__ kl, float kl_scale)
 {
     double tot = 0.0;
     for (int b = 0; b < blocks; ++b) tot += partials[b];
-    *loss = (float)(tot / (double)N);
+    const float ce = (float)(tot / (double)N);
+    loss[0] = ce;
+    if (kl) loss[1] = ce + kl[0] * kl_scale;
 }
 
 extern "C" int64_t snn_ce_loss_partials(int32_t n) { return n > 1024 ? CE_MAX_BLOCKS : 0; }
 
+// snn_ce_loss_grad, and -- with kl != NULL -- also loss[1] = CE + kl_scale * kl[0], the loss train_step returns for a
+// BayesianRNN (utils/training_utils.py:515-518): used by snn_train_step_grad, whose `loss` then holds two floats
+int snn_ce_loss_grad_total(int32_t n, int32_t n_classes, const float* logits, const int64_t* target, float grad_scale,
+                           float* loss, float* dlogits, double* partials, const float* kl, float kl_scale, void* stream);
 extern "C" int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float* logits, const int64_t* target,
                                 float grad_scale, float* loss, float* dlogits, double* partials, void* stream)
+{
+    return snn_ce_loss_grad_total(n, n_classes, logits, target, grad_scale, loss, dlogits, partials, nullptr, 0.0f, stream);
+}
+int snn_ce_loss_grad_total(int32_t n, int32_t n_classes, const float* logits, const int64_t* target, float grad_scale,
+                           float* loss, float* dlogits, double* partials, const float* kl, float kl_scale, void* stream)
 {
     if (!logits || !target || !loss || !dlogits || n < 1 || n_classes < 1) {
         snn_set_error("snn_ce_loss_grad: null pointer or bad size");
@@ -324,9 +340,9 @@ extern "C" int snn_ce_loss_grad(int32_t n, int32_t n_classes, const float* logit
         return SNN_ERR_ARG;
     }
     hipLaunchKernelGGL(ce_loss_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, n_classes, logits, target,
-                       grad_scale, loss, dlogits, partials);
+                       grad_scale, loss, dlogits, partials, kl, kl_scale);
     if (blocks > 1)
-        hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, n, blocks, partials, loss);
+        hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, n, blocks, partials, loss, kl, kl_scale);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
 }

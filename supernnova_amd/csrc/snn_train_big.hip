@@ -37,10 +37,10 @@ constexpr int PAD = 33;   // LDS row stride of transposed-read images
 // ---- weight images -------------------------------------------------------------------------------------
 // WT_hh[ld][mt][kk][lane] = W_hh_eff[R = 2kk + (lane >> 5)][j = 32 mt + (lane & 31)]       (mt < H/32, kk < 2H)
 // WT_ih[ld][mt][kk][lane] = W_ih[R][f = 32 mt + (lane & 31)]                               (layer >= 1, mt < I/32)
-__global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
+__device__ __forceinline__ void bwd_prep_body(const Bwd2Params& p, int bx, int nbx, int by)
 {
     const SnnLayout& y = p.lay;
-    const int ld = blockIdx.y >> 1, which = blockIdx.y & 1;   // 0: hh, 1: ih
+    const int ld = by >> 1, which = by & 1;   // 0: hh, 1: ih
     const int l = ld / y.dirs, d = ld - l * y.dirs;
     const int H = y.H, I = y.I[l];
     if (which == 1 && l == 0) return;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
     const int64_t n = (int64_t)(cols / 32) * 2 * H * 64;
     float* dst = p.WT + (which == 0 ? p.wt_hh[ld] : p.wt_ih[ld]);
     const bool masked = p.mk.mode != SNN_MASK_NONE;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)nbx * blockDim.x) {
         const int lane = (int)(idx & 63);
         const int kk = (int)((idx >> 6) % (2 * H));
         const int mt = (int)(idx / ((int64_t)2 * H * 64));
@@ -64,10 +64,9 @@ __global__ void __launch_bounds__(256) bwd_prep_kernel(const Bwd2Params p)
 }
 
 // ---- output layer backward ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) head_dfeat_kernel(const Bwd2Params p)
+__device__ __forceinline__ void head_dfeat_body(const Bwd2Params& p, int tile)
 {
     const SnnLayout& y = p.lay;
-    const int tile = blockIdx.x;
     const float* Wo = p.wk + y.k_head_w;
     float* out = p.dfeat + (int64_t)tile * y.F * 32;
     for (int idx = threadIdx.x; idx < y.F * 32; idx += blockDim.x) {
@@ -85,7 +84,7 @@ __global__ void __launch_bounds__(256) head_dfeat_kernel(const Bwd2Params p)
 // dW_out[q][f] = sum over curves dlogits[curve][q] feat[curve][f];  db_out[q] = sum dlogits.  One workgroup per output
 // element: thread k adds sorted positions k, k + 256, ... in order, then a fixed shuffle / LDS tree -- the order depends
 // on the batch only, never on scheduling.
-__global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p, int n_chunks)
+__device__ __forceinline__ void head_dw_body(const Bwd2Params& p, int n_chunks, int bx)
 {
     // n_chunks == 1: the sum goes straight to dflat.  n_chunks > 1 (streamed path, large batches): chunk ch adds its
     // share of the sorted positions into slab ch (the head entries of the gradient slabs are otherwise unused) and
@@ -93,7 +92,7 @@ __global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p, int n_
     __shared__ float sh[4];
     const SnnLayout& y = p.lay;
     const int n_out = y.C * y.F + y.C;
-    const int idx = blockIdx.x % n_out, ch = blockIdx.x / n_out;
+    const int idx = bx % n_out, ch = bx / n_out;
     const int64_t feat0 = (int64_t)y.L * y.dirs * p.max_T * tape_step_floats(y.H);
     const int npos = p.n_tiles * SNN_TILE;
     const int per = ((npos + n_chunks - 1) / n_chunks + 255) / 256 * 256;
@@ -119,6 +118,27 @@ __global__ void __launch_bounds__(256) head_dw_kernel(const Bwd2Params p, int n_
     }
 }
 
+// The three preparations of a backward -- transposed weight images, dfeat per tile, output-layer gradient -- depend only
+// on the forward's results and on each other not at all: ONE launch, a block range each (they were three launches of
+// ~5 us; a 128-curve step is ~25 launches).
+#define SNN_PREP_BX 64
+__global__ void __launch_bounds__(256) bwd_head_prep_kernel(const Bwd2Params p, int head_chunks)
+{
+    const SnnLayout& y = p.lay;
+    const int n_prep = SNN_PREP_BX * 2 * y.L * y.dirs;
+    int b = blockIdx.x;
+    if (b < n_prep) { bwd_prep_body(p, b % SNN_PREP_BX, SNN_PREP_BX, b / SNN_PREP_BX); return; }
+    b -= n_prep;
+    if (b < p.n_tiles) { head_dfeat_body(p, b); return; }
+    head_dw_body(p, head_chunks, b - p.n_tiles);
+}
+static void launch_head_prep(const Bwd2Params& p, int head_chunks, hipStream_t st)
+{
+    const SnnLayout& y = p.lay;
+    const int grid = SNN_PREP_BX * 2 * y.L * y.dirs + p.n_tiles + (y.C * y.F + y.C) * head_chunks;
+    hipLaunchKernelGGL(bwd_head_prep_kernel, dim3(grid), dim3(256), 0, st, p, head_chunks);
+}
+
 // ---- the recurrent part ------------------------------------------------------------------------------
 // CELL 0 LSTM (tape slots i, f, g, o, c, h), 1 GRU (r, z, n, W_hn h + b_hn, -, h), 2 tanh RNN (-, -, -, -, -, h).  The four
 // row groups of dG follow the kernel image: GRU  d(r pre), d(z pre), d(n pre), d(n pre) * r   (input / hidden part of n);
@@ -129,7 +149,7 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
     constexpr int MT = H / 32;          // output tiles of dh
     constexpr int KSPLIT = 4 / MT;      // waves sharing one output tile (split over the gate rows)
     constexpr int KW = 2 * H / KSPLIT;  // MFMA k-steps per wave
-    constexpr int UPT = H / 8;          // hidden units per thread in the element-wise stage
+    constexpr int UPT = H / 32;         // (hidden unit, 4 curves) items per thread in the element-wise stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dGl = smem;                  // [4H][32]  gate gradients of the running step (B operand image)
     float* red = dGl + 4 * H * 32;      // [KSPLIT][H][32]
@@ -140,9 +160,18 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
     const int T = p.tile_T[tile];
     const bool last_layer = l == y.L - 1;
-    const int c = tid & 31, jg = tid >> 5;
-    const int len = p.len_sorted[tile * SNN_TILE + c];
-    const float inv_len = 1.0f / (float)(len > 0 ? len : 1);
+    // Element-wise stage: a thread owns 4 CONSECUTIVE curves of hidden units jg, jg + 32, ...: every tape row, dy row
+    // and dG row is then read / written as one 16-byte word per thread (a step moved 24 loads + 16 stores of 4 bytes
+    // per thread before; with 4 waves pushing their addresses through the compute unit's one address unit those
+    // 40 instructions, not the 16 MFMAs, were the step's time at small batches).
+    const int c4 = (tid & 7) * 4, jg = tid >> 3;
+    int len[4];
+    float inv_len[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        len[k] = p.len_sorted[tile * SNN_TILE + c4 + k];
+        inv_len[k] = 1.0f / (float)(len[k] > 0 ? len[k] : 1);
+    }
     const int64_t ts = tape_step_floats(H);
     const float* tape_ld = p.tape + (int64_t)tile * p.tape_tile + (int64_t)ld * p.max_T * ts;
     const float* dfeat = p.dfeat + (int64_t)tile * y.F * 32;
@@ -156,29 +185,35 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) wT[kk] = A[kk * 64];
     }
-    float dc[UPT], dhr[UPT], dfm[UPT];
+    f32x4 dc[UPT], dhr[UPT], dfm[UPT];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-        const int j = jg + 8 * i;
-        dc[i] = 0.0f;
-        dhr[i] = y.pool == SNN_POOL_STANDARD ? dfeat[(j * (y.L * dirs) + ld) * 32 + c] : 0.0f;
-        dfm[i] = (last_layer && y.pool == SNN_POOL_MEAN) ? dfeat[(d * H + j) * 32 + c] * inv_len : 0.0f;
+        const int j = jg + 32 * i;
+        dc[i] = zero4;
+        dhr[i] = y.pool == SNN_POOL_STANDARD ? *reinterpret_cast<const f32x4*>(dfeat + (j * (y.L * dirs) + ld) * 32 + c4) : zero4;
+        dfm[i] = zero4;
+        if (last_layer && y.pool == SNN_POOL_MEAN) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dfeat + (d * H + j) * 32 + c4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dfm[i][k] = v[k] * inv_len[k];
+        }
     }
     // The tape rows (and dy) of a step are fetched one step ahead: the recurrence is a latency chain, and an
     // un-prefetched global load per step was most of it.  Rows t < T of the tape and of dy are always written
     // (forward / bwd_dx store every step of the tile), so the fetch needs no length test.
-    float n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cn[UPT], n_dy[UPT];
-    auto fetch = [&](int t) {
-        const float* tq = tape_ld + (int64_t)t * ts + c;
+    f32x4 n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cn[UPT], n_dy[UPT];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const float* tq = tape_ld + (int64_t)t * ts + c4;
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 8 * i;
-            n_ig[i] = tq[(0 * H + j) * 32];
-            n_fg[i] = tq[(1 * H + j) * 32];
-            n_gg[i] = tq[(2 * H + j) * 32];
-            n_og[i] = tq[(3 * H + j) * 32];
-            n_cn[i] = tq[((CELL == 0 ? 4 : 5) * H + j) * 32];   // LSTM: c_t; GRU / RNN: h_t
-            n_dy[i] = dy ? dy[(int64_t)t * H * 32 + j * 32 + c] : 0.0f;
+            const int j = jg + 32 * i;
+            n_ig[i] = *reinterpret_cast<const f32x4*>(tq + (0 * H + j) * 32);
+            n_fg[i] = *reinterpret_cast<const f32x4*>(tq + (1 * H + j) * 32);
+            n_gg[i] = *reinterpret_cast<const f32x4*>(tq + (2 * H + j) * 32);
+            n_og[i] = *reinterpret_cast<const f32x4*>(tq + (3 * H + j) * 32);
+            n_cn[i] = *reinterpret_cast<const f32x4*>(tq + ((CELL == 0 ? 4 : 5) * H + j) * 32);   // LSTM: c_t; GRU / RNN: h_t
+            n_dy[i] = dy ? *reinterpret_cast<const f32x4*>(dy + (int64_t)t * H * 32 + j * 32 + c4) : zero4;
         }
     };
     if (T > 0) fetch(d == 0 ? T - 1 : 0);
@@ -187,9 +222,7 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
         const int step = T - 1 - sb;
         const int t = d == 0 ? step : T - 1 - step;
         const int tp = d == 0 ? t - 1 : t + 1;
-        const bool valid = t < len;
-        const bool prev_live = step > 0 && tp < len;
-        float ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], dyv[UPT];
+        f32x4 ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], dyv[UPT];
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cn[i] = n_cn[i]; dyv[i] = n_dy[i];
@@ -197,48 +230,53 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
         if (step > 0) fetch(tp);   // n_cn is then c of the previous step: the cell state this step started from
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 8 * i;
-            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
-            if (valid && CELL != 0) {
-                float dh = dhr[i];
-                if (dy) dh += dyv[i];
-                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
-                if (CELL == 1) {   // h = (1 - z) n + z h_prev,  n = tanh(a2 + r a3)
-                    const float rg = ig[i], zg = fg[i], ng = gg[i], a3 = og[i];
-                    const float hp = prev_live ? n_cn[i] : 0.0f;
-                    const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
-                    dai = dnp * a3 * rg * (1.0f - rg);
-                    daf = dh * (hp - ng) * zg * (1.0f - zg);
-                    dag = dnp;
-                    dao = dnp * rg;
-                    dc[i] = dh * zg;        // the direct path to h_prev, added to W_hh^T dG below
-                } else {           // h = tanh(a0); cn[] holds h_t
-                    dai = dh * (1.0f - cn[i] * cn[i]);
-                    dc[i] = 0.0f;
+            const int j = jg + 32 * i;
+            f32x4 dai = zero4, daf = zero4, dag = zero4, dao = zero4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool valid = t < len[k];
+                const bool prev_live = step > 0 && tp < len[k];
+                if (valid && CELL != 0) {
+                    float dh = dhr[i][k];
+                    if (dy) dh += dyv[i][k];
+                    if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i][k];
+                    if (CELL == 1) {   // h = (1 - z) n + z h_prev,  n = tanh(a2 + r a3)
+                        const float rg = ig[i][k], zg = fg[i][k], ng = gg[i][k], a3 = og[i][k];
+                        const float hp = prev_live ? n_cn[i][k] : 0.0f;
+                        const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
+                        dai[k] = dnp * a3 * rg * (1.0f - rg);
+                        daf[k] = dh * (hp - ng) * zg * (1.0f - zg);
+                        dag[k] = dnp;
+                        dao[k] = dnp * rg;
+                        dc[i][k] = dh * zg;        // the direct path to h_prev, added to W_hh^T dG below
+                    } else {           // h = tanh(a0); cn[] holds h_t
+                        dai[k] = dh * (1.0f - cn[i][k] * cn[i][k]);
+                        dc[i][k] = 0.0f;
+                    }
+                }
+                if (valid && CELL == 0) {
+                    float dh = dhr[i][k];
+                    if (dy) dh += dyv[i][k];
+                    if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i][k];
+                    const float cp = prev_live ? n_cn[i][k] : 0.0f;
+                    const float tc = snn_tanh(cn[i][k]);
+                    const float dct = dc[i][k] + dh * og[i][k] * (1.0f - tc * tc);
+                    dao[k] = dh * tc * og[i][k] * (1.0f - og[i][k]);
+                    dai[k] = dct * gg[i][k] * ig[i][k] * (1.0f - ig[i][k]);
+                    daf[k] = dct * cp * fg[i][k] * (1.0f - fg[i][k]);
+                    dag[k] = dct * ig[i][k] * (1.0f - gg[i][k] * gg[i][k]);
+                    dc[i][k] = dct * fg[i][k];
                 }
             }
-            if (valid && CELL == 0) {
-                float dh = dhr[i];
-                if (dy) dh += dyv[i];
-                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i];
-                const float cp = prev_live ? n_cn[i] : 0.0f;
-                const float tc = snn_tanh(cn[i]);
-                const float dct = dc[i] + dh * og[i] * (1.0f - tc * tc);
-                dao = dh * tc * og[i] * (1.0f - og[i]);
-                dai = dct * gg[i] * ig[i] * (1.0f - ig[i]);
-                daf = dct * cp * fg[i] * (1.0f - fg[i]);
-                dag = dct * ig[i] * (1.0f - gg[i] * gg[i]);
-                dc[i] = dct * fg[i];
-            }
-            dGl[(0 * H + j) * 32 + c] = dai;
-            dGl[(1 * H + j) * 32 + c] = daf;
-            dGl[(2 * H + j) * 32 + c] = dag;
-            dGl[(3 * H + j) * 32 + c] = dao;
-            float* o = dGg + (int64_t)t * 4 * H * 32 + j * 32 + c;
-            o[0 * H * 32] = dai;
-            o[1 * H * 32] = daf;
-            o[2 * H * 32] = dag;
-            o[3 * H * 32] = dao;
+            *reinterpret_cast<f32x4*>(dGl + (0 * H + j) * 32 + c4) = dai;
+            *reinterpret_cast<f32x4*>(dGl + (1 * H + j) * 32 + c4) = daf;
+            *reinterpret_cast<f32x4*>(dGl + (2 * H + j) * 32 + c4) = dag;
+            *reinterpret_cast<f32x4*>(dGl + (3 * H + j) * 32 + c4) = dao;
+            float* o = dGg + (int64_t)t * 4 * H * 32 + j * 32 + c4;
+            *reinterpret_cast<f32x4*>(o + 0 * H * 32) = dai;
+            *reinterpret_cast<f32x4*>(o + 1 * H * 32) = daf;
+            *reinterpret_cast<f32x4*>(o + 2 * H * 32) = dag;
+            *reinterpret_cast<f32x4*>(o + 3 * H * 32) = dao;
         }
         __syncthreads();
         // dh_{prev}[j'][curve] = sum_R W_hh[R][j'] dG[R][curve]: this wave's output tile mt, gate rows of split ks
@@ -254,15 +292,19 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
                 red[((ks * H) + 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * hf) * 32 + cl] = acc[i];
         }
         __syncthreads();
-        if (valid) {   // beyond the curve the state is frozen: the gradient passes through unchanged
 #pragma unroll
-            for (int i = 0; i < UPT; ++i) {
-                const int j = jg + 8 * i;
-                float s = 0.0f;
+        for (int i = 0; i < UPT; ++i) {
+            const int j = jg + 32 * i;
+            f32x4 s = zero4;
 #pragma unroll
-                for (int k = 0; k < KSPLIT; ++k) s += red[(k * H + j) * 32 + c];
-                dhr[i] = CELL == 1 ? s + dc[i] : s;
+            for (int k = 0; k < KSPLIT; ++k) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(red + (k * H + j) * 32 + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += r[e];
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)      // beyond the curve the state is frozen: the gradient passes through unchanged
+                if (t < len[e]) dhr[i][e] = CELL == 1 ? s[e] + dc[i][e] : s[e];
         }
     }
 }
@@ -508,7 +550,17 @@ __global__ void __launch_bounds__(256) chunk_reduce_kernel(int64_t n, int64_t P,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? out[i] : 0.0f;
-    for (int k = 0; k < n_chunks; ++k) s += slabs[(int64_t)k * P + i];
+    // loads in batches of 8 (independent, in flight together), additions in index order: one dependent load per chunk
+    // made this 20 us for the 80 chunks of a 128-curve batch
+    int k = 0;
+    for (; k + 8 <= n_chunks; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = slabs[(int64_t)(k + e) * P + i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+    }
+    for (; k < n_chunks; ++k) s += slabs[(int64_t)k * P + i];
     out[i] = s;
 }
 
@@ -582,7 +634,8 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     // weight-gradient partial sums: one slab of P floats per chunk of tile-steps; up to 256 chunks while the slabs stay
     // under 64 MB (small models, large batches), never fewer than the 64 the large models ran with
     const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(256, ((int64_t)64 << 20) / ((int64_t)sizeof(float) * y.P)));
-    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, total / 2));
+    // (a chunk is at least ~8 tile-steps: every chunk costs a slab of P floats that chunk_reduce_kernel reads back)
+    g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, std::max<int64_t>(total / 8, std::min<int64_t>(total / 2, 16))));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
 }
@@ -655,11 +708,9 @@ int snn_lstm_backward_stream(const SnnLayout& y, const float* xp, const int32_t*
     p.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
     const int n_ld = y.L * y.dirs;
-    hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
     // output-layer gradient: one chunk of sorted positions per 2048 curves, at most one per gradient slab
     const int head_chunks = std::max(1, std::min(y.dirs * g.G, p.n_tiles * SNN_TILE / 2048));
-    hipLaunchKernelGGL(head_dw_kernel, dim3((y.C * y.F + y.C) * head_chunks), dim3(256), 0, st, p, head_chunks);
+    launch_head_prep(p, head_chunks, st);
     HIP_CHECK(hipGetLastError());
     for (int l = y.L - 1; l >= 0; --l) {
         const bool first = l == 0;
@@ -700,9 +751,7 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     Bwd2Params p = p0;
     const SnnLayout& y = p.lay;
     const int n_ld = y.L * y.dirs;
-    hipLaunchKernelGGL(bwd_prep_kernel, dim3(64, 2 * n_ld), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dfeat_kernel, dim3(p.n_tiles), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(head_dw_kernel, dim3(y.C * y.F + y.C), dim3(256), 0, st, p, 1);
+    launch_head_prep(p, 1, st);
     HIP_CHECK(hipGetLastError());
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);

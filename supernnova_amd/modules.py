@@ -242,12 +242,14 @@ class _HipRNN(nn.Module):
         Data parallel (torch.distributed initialised, `global_batch` = curves of ALL ranks in this step): every curve's
         CE gradient is weighted 1 / global_batch and the rank-identical KL gradient 1 / world, and the ranks' flat
         gradients are SUMMED -- the single-process gradient for any split of the batch, equal shards or not."""
+        tl = self.__dict__.get("_timeline")      # measurement hook (bench_train.py): [(phase name, event)] per step
+        if tl is None and masks is None:
+            return self._train_step_one_call(x, target, optimizer, kl_scale, eps, global_batch)
         padded, lengths = self._unpack(x)
         if not self.cfg.supported():
             raise L.SnnError(f"no HIP kernel for this configuration: {self.cfg}")
         cfg, dev = self.cfg, padded.device
         self.flat_parameters()
-        tl = self.__dict__.get("_timeline")      # measurement hook (bench_train.py): [(phase name, event)] per step
 
         def mark(name):
             if tl is not None:
@@ -298,6 +300,113 @@ class _HipRNN(nn.Module):
         mark("allreduce+adam")
         self.last_logits = logits
         return loss
+
+    def _train_step_one_call(self, x, target, optimizer, kl_scale, eps, global_batch):
+        """fused_train_step through snn_train_step_grad: the same launches as the call-by-call sequence above, enqueued
+        by ONE call of the C ABI into buffers that are kept between steps (grown on demand; every consumer is ordered
+        behind its producer on the current stream).  What is allocated per step is what the caller may keep: the
+        logits, and one small tensor holding the loss and the KL."""
+        import ctypes
+        import os
+        from .distributed import world_size
+        padded, lengths = self._unpack(x)
+        cfg = self.cfg
+        dev = padded.device
+        st = self.__dict__.get("_train_state")
+        if st is None or st["dev"] != dev:
+            if not cfg.supported():
+                raise L.SnnError(f"no HIP kernel for this configuration: {cfg}")
+            st = {"dev": dev, "cfgc": cfg.c, "P": cfg.P, "PK": cfg.PK, "C": cfg.nb_classes, "nt": cfg.n_tensors,
+                  "xsf": cfg.x_step_floats, "io": L.SnnTrainIO(), "sizes": {}, "bufs": {},
+                  "prior": self._prior.c if isinstance(self, BayesianRNN) else None}
+            self.__dict__["_train_state"] = st
+        flat = self.flat_parameters()
+        bayes = st["prior"] is not None
+        lib, io, P, C = L.load(), st["io"], st["P"], st["C"]
+        plan = E.Plan(cfg, lengths, dev)
+        N = plan.n_curves
+        if target.dtype != torch.int64 or not target.is_cuda or target.numel() != N:
+            raise L.SnnError("target must be a device int64 tensor with one entry per curve")
+        target = target.contiguous()
+        key = (plan.n_tiles, plan.max_T, os.environ.get("SNN_BWD_PATH"), os.environ.get("SNN_FWD_SPLIT"))
+        sz = st["sizes"].get(key)
+        if sz is None:
+            cref = ctypes.byref(st["cfgc"])
+            sz = (L.check(lib.snn_train_tape_floats(cref, plan.n_tiles, plan.max_T), "snn_train_tape_floats"),
+                  L.check(lib.snn_lstm_forward_workspace_bytes(cref, plan.max_T), "snn_lstm_forward_workspace_bytes"),
+                  L.check(lib.snn_lstm_backward_workspace_bytes(cref, plan.n_tiles, plan.max_T), "snn_lstm_backward_workspace_bytes"))
+            st["sizes"][key] = sz
+        tape_floats, fwd_bytes, bwd_bytes = sz
+
+        def buf(name, n, dtype=torch.float32):
+            t = st["bufs"].get(name)
+            if t is None or t.numel() < n:
+                t = torch.empty(int(n * 1.25) + 64, dtype=dtype, device=dev)
+                st["bufs"][name] = t
+            return t
+        xp_floats = plan.total_steps * st["xsf"]
+        n_part = lib.snn_ce_loss_partials(N)
+        poff = (4 + 3 * st["nt"] + 1) & ~1          # fp64 partials of the CE sum: 8-byte aligned
+        small = torch.empty(poff + 2 * n_part, dtype=torch.float32, device=dev)   # [CE, loss, KL, -, kl_terms..., partials...]
+        logits = torch.empty((N, C), dtype=torch.float32, device=dev)
+        xp, wk, tape = buf("xp", xp_floats), buf("wk", st["PK"]), buf("tape", tape_floats)
+        dlogits, dw = buf("dlogits", N * C), buf("dw", P)
+        fwd_ws, bwd_ws = buf("fwd_ws", fwd_bytes, torch.uint8), buf("bwd_ws", bwd_bytes, torch.uint8)
+        world = world_size(getattr(optimizer, "process_group", None))
+        dp = world > 1 and global_batch is not None
+        if dp and not (N <= global_batch):
+            raise ValueError(f"fused_train_step: this rank holds {N} curves but global_batch is {global_batch}")
+        io.x, io.step_off, io.stride_t, io.stride_n = padded.data.data_ptr(), None, 0, cfg.input_size
+        if isinstance(padded, E.PackedRows):
+            io.step_off = padded.step_off.data_ptr()
+            io.curve_off = None if padded.col_off is None else padded.col_off.data_ptr()
+        else:      # dense (T, B, D)
+            io.x, io.curve_off = padded.data_ptr(), None
+            io.stride_t, io.stride_n = N * cfg.input_size, cfg.input_size
+        io.order, io.len_sorted = plan.d_order.data_ptr(), plan.d_len_sorted.data_ptr()
+        io.tile_T, io.tile_off = plan.d_tile_T.data_ptr(), plan.d_tile_off.data_ptr()
+        io.n_curves, io.n_tiles, io.max_T, io.xp_floats = N, plan.n_tiles, plan.max_T, xp_floats
+        io.target = target.data_ptr()
+        mc = None
+        if bayes:
+            (a0, a1), (b0, b1) = self._slices["mu"], self._slices["rho"]
+            mu, rho = flat[a0:a1], flat[b0:b1]
+            if eps is None and self.draws == "host":
+                eps = self.host_eps(1, dev)
+            if eps is not None:
+                eps = eps.reshape(-1).contiguous()
+                if eps.numel() != P - C or not eps.is_cuda:
+                    raise L.SnnError(f"eps must hold {P - C} floats on the GPU")
+            io.params, io.rho = mu.data_ptr(), rho.data_ptr()
+            io.eps = None if eps is None else eps.data_ptr()
+            io.bbb_mode = L.BBB_EPS if eps is not None else L.BBB_PHILOX
+            io.seed, io.offset = (0 if eps is not None else self._seed()), 0
+            io.prior = ctypes.pointer(st["prior"])
+            io.kl, io.kl_terms = small[2:].data_ptr(), small[4:].data_ptr()
+            gflat = buf("grad", 2 * P - C)
+            io.grad = gflat.data_ptr()
+            io.masks = None
+        else:
+            io.params, io.rho, io.eps = flat.data_ptr(), None, None
+            masks = self._masks(plan) if isinstance(self, VanillaRNN) else self._masks(1, N, dev, False)
+            mc = masks.c() if masks is not None and masks.mode != L.SNN_MASK_NONE else None
+            io.masks = ctypes.pointer(mc) if mc is not None else None
+            gflat, io.grad = dw, None
+        io.ce_grad_scale = 1.0 / global_batch if dp else 1.0 / N
+        io.kl_scale = kl_scale / world if dp else kl_scale
+        io.loss_kl_scale = kl_scale
+        io.xp, io.wk, io.logits, io.tape, io.tape_floats = xp.data_ptr(), wk.data_ptr(), logits.data_ptr(), tape.data_ptr(), tape.numel()
+        io.dlogits, io.loss, io.dw = dlogits.data_ptr(), small.data_ptr(), dw.data_ptr()
+        io.ce_partials = small[poff:].data_ptr() if n_part else None
+        io.fwd_ws, io.fwd_ws_bytes, io.bwd_ws, io.bwd_ws_bytes = fwd_ws.data_ptr(), fwd_ws.numel(), bwd_ws.data_ptr(), bwd_ws.numel()
+        L.check(lib.snn_train_step_grad(ctypes.byref(st["cfgc"]), ctypes.byref(io), E._stream()), "snn_train_step_grad")
+        n_grad = (2 * P - C) if bayes else P
+        optimizer.step_flat(gflat[:n_grad], mean=not dp)
+        self.last_logits = logits
+        if bayes:
+            self.kl = small[2]
+            return small[1]
+        return small[0]
 
     def _launch(self, x, wk, n_samples, masks=None, want_probs=False):
         padded, lengths = self._unpack(x)

@@ -651,3 +651,37 @@ def test_small_batches_take_the_split_forward_by_default():
         wk = E.prepare_weights(cfg, torch.zeros(cfg.P, device=DEV))
         E.lstm_forward_train(cfg, plan, xp, wk, None)
         assert ("fwd_gx_kernel" in E.last_forward_kernel()) == want, E.last_forward_kernel()
+
+
+@pytest.mark.parametrize("model", ["vanilla", "variational", "bayesian"])
+def test_one_call_train_step_equals_the_call_by_call_sequence(model):
+    """snn_train_step_grad enqueues the launches of the separate entry points from ONE call into buffers kept between
+    steps: three steps through it leave bit-identical parameters, losses and KL as three steps through the call-by-call
+    sequence (which bench_train's phase timing still uses), on batches of changing size and length."""
+    from test_host_logic import settings
+    from supernnova_amd.utils import training_utils as tu
+    st = settings(model=model, dropout=0.1 if model != "bayesian" else 0.0)
+    g = np.random.default_rng(21)
+    batches = []
+    for B, T in ((128, 40), (37, 12), (200, 25)):
+        lengths = np.sort(g.integers(1, T + 1, size=B))[::-1].copy()
+        x = g.standard_normal((int(lengths[0]), B, 24)).astype(np.float32)
+        for b in range(B):
+            x[lengths[b]:, b] = 0
+        pk = pack_padded_sequence(torch.from_numpy(x).to(DEV), torch.from_numpy(lengths.astype(np.int64)))
+        batches.append((pk, torch.from_numpy(g.integers(0, 2, size=B)).to(DEV), B))
+    out = []
+    for one_call in (True, False):
+        torch.manual_seed(5)
+        rnn = tu.get_model(st, 24).to(DEV)
+        opt = tu.get_optimizer(st, rnn)
+        losses = []
+        for pk, tg, B in batches:
+            if not one_call:
+                rnn._timeline = []            # the measurement hook selects the call-by-call sequence
+            losses.append(float(tu.train_step_fused(st, rnn, pk, tg, opt, B, 100)))
+            if model == "bayesian":
+                losses.append(float(rnn.kl))
+        out.append((rnn.flat_parameters().detach().clone(), losses))
+    assert torch.equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-6)
