@@ -256,9 +256,12 @@ int snn_prepare_weights_multi(const snn_cfg *cfg, const float *flat, int64_t sam
  *   mode: 0 = use eps; 1 = mean_field_inference (w = mu, :486-488); 2 = Philox N(0,1)
  *         keyed by (seed, offset + s, parameter index)
  *   wk  (S, PK)  out: kernel-layout weights;  kl (S) out, may be NULL
- *   kl_terms     S*(4*L*dirs+1)*3 floats (caller-owned), may be NULL iff kl is NULL: per sample and
- *                tensor (KL term, r1, r2) with r_k the mixture responsibilities snn_bbb_backward needs
+ *   kl_terms     snn_kl_terms_floats(cfg, S) floats (caller-owned, 8-byte aligned), may be NULL iff kl is NULL: first,
+ *                per sample and tensor, (KL term, r1, r2) with r_k the mixture responsibilities snn_bbb_backward needs
+ *                -- S*(4*L*dirs+1)*3 floats --, then the scratch of the per-tensor sums (fp64 partial sums of the
+ *                workgroups a tensor is dealt over; added in index order: the KL does not depend on scheduling)
  */
+int64_t snn_kl_terms_floats(const snn_cfg *cfg, int32_t n_samples);
 int snn_bbb_sample(const snn_cfg *cfg, const float *mu, const float *rho, const float *eps,
                    int32_t mode, uint64_t seed, uint64_t offset, int32_t n_samples,
                    const snn_prior *prior, float *wk, float *kl, float *kl_terms, void *stream);
@@ -415,7 +418,7 @@ int snn_sgd_step(int64_t n, float *params, const float *grads, float *momentum_b
  *   ce_grad_scale   dlogits = ce_grad_scale * (softmax - onehot): 1 / n_curves, or 1 / global batch under data parallelism
  *   kl_scale        weight of the KL gradient (1 / (num_batches * batch_size), divided by the world size under DP)
  *   loss_kl_scale   weight of the KL term in the reported loss (1 / (num_batches * batch_size))
- *   out: xp (xp_floats), wk (PK), kl (1) + kl_terms ((4 L dirs + 1) * 3) [Bayesian], logits (n_curves, C), tape
+ *   out: xp (xp_floats), wk (PK), kl (1) + kl_terms (snn_kl_terms_floats(cfg, 1)) [Bayesian], logits (n_curves, C), tape
  *        (snn_train_tape_floats), dlogits (n_curves, C), loss (2 floats: mean CE of this batch, and for BayesianRNN
  *        CE + loss_kl_scale * KL), ce_partials (snn_ce_loss_partials doubles, may be NULL for n <= 1024), dw (P: the
  *        gradient w.r.t. the weight set -- for VanillaRNN / VariationalRNN THE gradient), grad (BayesianRNN only:

@@ -91,6 +91,7 @@ SIGNATURES = {
     "snn_prepare_weights_multi": (ctypes.c_int, [_CFG, _P, ctypes.c_int64, ctypes.c_int32, _P, _P]),
     "snn_bbb_sample": (ctypes.c_int, [_CFG, _P, _P, _P, ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                       ctypes.c_int32, ctypes.POINTER(SnnPrior), _P, _P, _P, _P]),
+    "snn_kl_terms_floats": (ctypes.c_int64, [_CFG, ctypes.c_int32]),
     "snn_lstm_forward_workspace_bytes": (ctypes.c_int64, [_CFG, ctypes.c_int32]),
     "snn_lstm_forward": (ctypes.c_int, [_CFG, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_int32, _P, ctypes.c_int64, ctypes.c_int32,

@@ -145,15 +145,21 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
     a = sa; b = sb; c = sc;
 }
 
-__global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
+// chunks a tensor's elements are dealt over (one workgroup each): a training step samples ONE weight set, and with a
+// workgroup per tensor the 8192 elements of the largest one (Philox + Box-Muller + softplus + three log-densities each)
+// were a 26 us chain on one compute unit
+#define SNN_BBB_NCH 8
+__host__ __device__ inline int64_t kl_final_floats(int n_tensors, int S) { return ((int64_t)S * n_tensors * 3 + 1) & ~(int64_t)1; }
+
+__global__ void __launch_bounds__(256) bbb_sample_kernel(SnnLayout y, const float* __restrict__ mu,
                                                         const float* __restrict__ rho,
                                                         const float* __restrict__ eps, int mode,
                                                         uint64_t seed, uint64_t offset, snn_prior prior,
                                                         float* __restrict__ wk, float* __restrict__ kl_terms,
-                                                        int64_t mu_stride)
+                                                        int64_t mu_stride, int S)
 {
     __shared__ double sh[48];
-    const int tau = blockIdx.x, s = blockIdx.y;
+    const int tau = blockIdx.x, s = blockIdx.y, ch = blockIdx.z;
     mu += (int64_t)s * mu_stride;   // snn_prepare_weights_multi: one canonical weight set per sample
     const TensorGeom g = tensor_geom(y, tau);
     const int64_t Ps = y.P - y.C;
@@ -165,7 +171,13 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
     const float s2 = g.kind == 4 ? prior.sigma2_out : prior.sigma2;
     const float v1 = s1 * s1, v2 = s2 * s2, l1 = logf(s1), l2 = logf(s2);
     double q = 0, p1 = 0, p2 = 0;
-    for (int i = threadIdx.x; i < (int)g.n; i += blockDim.x) {
+    const int n = (int)g.n, per = (n + SNN_BBB_NCH - 1) / SNN_BBB_NCH;
+    const int i1 = min(n, (ch + 1) * per);
+    if (tau == y.n_tensors && ch == 0 && threadIdx.x < 4) {      // alignment words behind the head bias
+        const int64_t at = y.k_head_b + y.C + threadIdx.x;
+        if (at < y.PK) dst[at] = 0.0f;
+    }
+    for (int i = ch * per + threadIdx.x; i < i1; i += blockDim.x) {
         const int64_t p = g.cbase + i;
         const float m = mu[p];
         float w = m;
@@ -196,7 +208,7 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
         } else if (y.prec == 2 && g.kind <= 1) {
             // the row's gate factor goes into the weight (one fp32 rounding), then the two fp16 pieces
             _Float16 wh, wl;
-            split2(__fmul_rn(w, h2_gate_scale((int)(i / g.cols) / y.H)), wh, wl);
+            split2(__fmul_rn(w, h2_gate_scale((i / g.cols) / y.H)), wh, wl);
             _Float16* d2 = reinterpret_cast<_Float16*>(dst) + kernel_index3(y, g, i);
             d2[0] = wh;
             d2[64 * 8] = wl;
@@ -204,32 +216,44 @@ __global__ void __launch_bounds__(1024) bbb_sample_kernel(SnnLayout y, const flo
             dst[kernel_index(y, g, i)] = w;
         }
     }
-    if (kl_terms != nullptr && g.kind != 5) {
+    if (want_kl) {      // this chunk's three log-probability sums (f64), added up per tensor by kl_finish_kernel
         block_sum3(q, p1, p2, sh);
         if (threadIdx.x == 0) {
-            float term = 0.0f, r1 = 0.0f, r2 = 0.0f;
-            if (sampled) {
-                const float m1 = (float)p1 + logf(prior.pi), m2 = (float)p2 + logf(1.0f - prior.pi);
-                const float mx = fmaxf(m1, m2);
-                const float lse = mx + logf(expf(m1 - mx) + expf(m2 - mx));
-                term = (float)q - lse;
-                r1 = expf(m1 - lse);  // mixture responsibilities: d logsumexp / d m_k (used by snn_bbb_backward)
-                r2 = expf(m2 - lse);
-            }
-            float* o = kl_terms + ((int64_t)s * y.n_tensors + tau) * 3;
-            o[0] = term; o[1] = r1; o[2] = r2;
+            double* part = reinterpret_cast<double*>(kl_terms + kl_final_floats(y.n_tensors, S)) +
+                           (((int64_t)s * y.n_tensors + tau) * SNN_BBB_NCH + ch) * 3;
+            part[0] = q; part[1] = p1; part[2] = p2;
         }
     }
 }
 
-// kl[s] = fp32 running sum over tensors in reference order (bayesian_rnn.py:501-528, 137)
-__global__ void kl_sum_kernel(int n_tensors, int S, const float* __restrict__ terms, float* __restrict__ kl)
+// per sample: chunk sums -> per-tensor KL term and mixture responsibilities (sum-then-logsumexp, bayesian_rnn.py:810-813),
+// then kl[s] = fp32 running sum over tensors in reference order (bayesian_rnn.py:501-528, 137)
+__global__ void __launch_bounds__(64) kl_finish_kernel(int n_tensors, int S, snn_prior prior, float* __restrict__ terms,
+                                                      float* __restrict__ kl)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    float acc = 0.0f;
-    for (int t = 0; t < n_tensors; ++t) acc = __fadd_rn(acc, terms[((int64_t)s * n_tensors + t) * 3]);
-    kl[s] = acc;
+    __shared__ float sh_term[64];
+    const int s = blockIdx.x, tau = threadIdx.x;
+    if (tau < n_tensors) {
+        const double* part = reinterpret_cast<const double*>(terms + kl_final_floats(n_tensors, S)) +
+                             ((int64_t)s * n_tensors + tau) * SNN_BBB_NCH * 3;
+        double q = 0, p1 = 0, p2 = 0;
+        for (int ch = 0; ch < SNN_BBB_NCH; ++ch) { q += part[ch * 3]; p1 += part[ch * 3 + 1]; p2 += part[ch * 3 + 2]; }
+        const float m1 = (float)p1 + logf(prior.pi), m2 = (float)p2 + logf(1.0f - prior.pi);
+        const float mx = fmaxf(m1, m2);
+        const float lse = mx + logf(expf(m1 - mx) + expf(m2 - mx));
+        const float term = (float)q - lse;
+        float* o = terms + ((int64_t)s * n_tensors + tau) * 3;
+        o[0] = term;
+        o[1] = expf(m1 - lse);  // mixture responsibilities: d logsumexp / d m_k (used by snn_bbb_backward)
+        o[2] = expf(m2 - lse);
+        sh_term[tau] = term;
+    }
+    __syncthreads();
+    if (tau == 0) {
+        float acc = 0.0f;
+        for (int t = 0; t < n_tensors; ++t) acc = __fadd_rn(acc, sh_term[t]);
+        kl[s] = acc;
+    }
 }
 
 // Head of the per-layer training forward (lstm_fwd_train_layer_kernel): per curve, the per-wave partial logits of the
@@ -285,6 +309,9 @@ fwd_rec_kernel_t snn_big_rec_kernel(int H, int KKI0, int dirs);   // snn_forward
 bool snn_gx_supported(const SnnLayout& y);
 int64_t snn_gx_floats(const SnnLayout& y, int n_tiles, int max_T);
 int snn_launch_gx(const SnnLayout& y, const FwdParams& p, int l, float* gx, int cus, hipStream_t st);
+// snn_rec16.hip: the recurrent half on half tiles (16 curves per workgroup), LSTM, H = 32 / 64
+bool snn_rec16_supported(const SnnLayout& y);
+int snn_launch_fwd_rec16(const SnnLayout& y, const FwdParams& p, int l, float* head_part, const float* gx, hipStream_t st);
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
@@ -391,17 +418,26 @@ static int launch_sample(const SnnLayout& y, const float* mu, const float* rho, 
                          uint64_t seed, uint64_t offset, int S, const snn_prior& prior, float* wk, float* kl,
                          float* kl_terms, hipStream_t st, int64_t mu_stride = 0)
 {
-    if (y.PK != y.k_head_b + y.C || y.Dp != y.D || y.prec != 0 || y.cell != 0)  // padding words exist: define them
-        HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));
-    // a training step samples ONE weight set: 22 workgroups, so make them wide (the per-tensor loop is a latency chain)
-    hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S), dim3(S < 8 ? 1024 : 256), 0, st, y, mu, rho, eps, mode, seed,
-                       offset, prior, wk, kl ? kl_terms : nullptr, mu_stride);
+    if (y.Dp != y.D || y.prec != 0 || y.cell != 0)  // padding words inside the image: define them (the alignment words
+        HIP_CHECK(hipMemsetAsync(wk, 0, sizeof(float) * (size_t)y.PK * S, st));   // at the tail are written by the kernel)
+    if (y.n_tensors > 64) { snn_set_error("snn_bbb_sample: %d tensors (more than 64)", y.n_tensors); return SNN_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bbb_sample_kernel, dim3(y.n_tensors + 1, S, SNN_BBB_NCH), dim3(256), 0, st, y, mu, rho, eps, mode, seed,
+                       offset, prior, wk, kl ? kl_terms : nullptr, mu_stride, S);
     HIP_CHECK(hipGetLastError());
     if (kl) {
-        hipLaunchKernelGGL(kl_sum_kernel, dim3((S + 63) / 64), dim3(64), 0, st, y.n_tensors, S, kl_terms, kl);
+        hipLaunchKernelGGL(kl_finish_kernel, dim3(S), dim3(64), 0, st, y.n_tensors, S, prior, kl_terms, kl);
         HIP_CHECK(hipGetLastError());
     }
     return SNN_OK;
+}
+
+extern "C" int64_t snn_kl_terms_floats(const snn_cfg* cfg, int32_t n_samples)
+{
+    SnnLayout y;
+    int rc = snn_make_layout(cfg, &y);
+    if (rc) return rc;
+    if (n_samples < 1) { snn_set_error("snn_kl_terms_floats: n_samples < 1"); return SNN_ERR_ARG; }
+    return kl_final_floats(y.n_tensors, n_samples) + (int64_t)n_samples * y.n_tensors * SNN_BBB_NCH * 3 * 2;
 }
 
 extern "C" int snn_prepare_weights(const snn_cfg* cfg, const float* flat, float* wk, void* stream)
@@ -446,7 +482,10 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
         snn_set_error("snn_bbb_sample: mode %d invalid or eps missing", mode);
         return SNN_ERR_ARG;
     }
-    if (kl && !kl_terms) { snn_set_error("snn_bbb_sample: kl requested without kl_terms scratch"); return SNN_ERR_ARG; }
+    if (kl && (!kl_terms || ((uintptr_t)kl_terms & 7))) {
+        snn_set_error("snn_bbb_sample: kl requested without kl_terms scratch (snn_kl_terms_floats floats, 8-byte aligned)");
+        return SNN_ERR_ARG;
+    }
     if (!(prior->pi > 0.f && prior->pi < 1.f) || !(prior->sigma1 > 0.f) || !(prior->sigma2 > 0.f) ||
         !(prior->sigma1_out > 0.f) || !(prior->sigma2_out > 0.f)) {
         snn_set_error("snn_bbb_sample: prior out of range");
@@ -750,12 +789,17 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
             const size_t lds = e->big ? sizeof(float) * ((size_t)3 * y.H * 32 + (size_t)5 * y.C * 32) + 16
                                       : sizeof(float) * ((size_t)2 * SNN_TAPE_Q * y.H * 32 + (size_t)2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
             HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_rec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // while even the half tiles get a compute unit each: 16 curves per workgroup (snn_rec16.hip), half the chain
+            // per step.  SNN_REC16=0|1 forces it off / on (A/B, tests); the backward follows the same rule.
+            const char* f16 = getenv("SNN_REC16");
+            const bool rec16 = snn_rec16_supported(y) && (f16 ? f16[0] == '1' : (int64_t)n_tiles * y.dirs * 2 <= g.cus);
             snprintf(g_last_kernel, sizeof(g_last_kernel), "fwd_gx_kernel + %s<%d,%d,%d,cell%d> x %d layers grid=%d block=%d lds=%zu",
-                     e->big ? "lstm_fwd_big_rec_kernel" : "lstm_fwd_rec_kernel", y.H, y.KKI[0], y.dirs, y.cell, y.L,
-                     n_tiles * y.dirs, g.threads, lds);
+                     rec16 ? "lstm_fwd_rec16_kernel" : e->big ? "lstm_fwd_big_rec_kernel" : "lstm_fwd_rec_kernel", y.H, y.KKI[0],
+                     y.dirs, y.cell, y.L, n_tiles * y.dirs * (rec16 ? 2 : 1), g.threads, lds);
             for (int l = 0; l < y.L; ++l) {
                 if ((rc = snn_launch_gx(y, p, l, gx, g.cus, st))) return rc;
-                hipLaunchKernelGGL(e->fn_rec, dim3(n_tiles * y.dirs), dim3(g.threads), lds, st, p, l, head_part, (const float*)gx);
+                if (rec16) { if ((rc = snn_launch_fwd_rec16(y, p, l, head_part, gx, st))) return rc; }
+                else hipLaunchKernelGGL(e->fn_rec, dim3(n_tiles * y.dirs), dim3(g.threads), lds, st, p, l, head_part, (const float*)gx);
             }
             hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, n_part, y.dirs, y.k_head_b, head_part);
             HIP_CHECK(hipGetLastError());

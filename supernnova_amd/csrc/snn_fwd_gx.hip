@@ -167,10 +167,10 @@ int snn_launch_gx(const SnnLayout& y, const FwdParams& p, int l, float* gx, int 
     g.H = y.H; g.dirs = y.dirs; g.l = l; g.KK = y.KK[l];
     g.n_rg = (y.H / 8 + 3) / 4;
     for (int d = 0; d < y.dirs; ++d) { g.k_A[d] = y.k_A[l * y.dirs + d]; g.k_bias[d] = y.k_bias[l * y.dirs + d]; }
-    // chunks of steps: enough workgroups for ~2 per compute unit, at least 2 steps per chunk (each workgroup loads its
+    // chunks of steps: enough workgroups for ~2 per compute unit, (each workgroup loads its
     // rows of W_ih once and amortises them over the chunk; a chunk's steps are a chain of dependent memory round trips)
     const int64_t base = (int64_t)p.n_tiles * y.dirs * g.n_rg;
-    int n_tchunks = (int)std::max<int64_t>(1, std::min<int64_t>((p.max_T + 1) / 2, (2 * (int64_t)cus + base - 1) / base));
+    int n_tchunks = (int)std::max<int64_t>(1, std::min<int64_t>(p.max_T, (2 * (int64_t)cus + base - 1) / base));
     g.TC = (p.max_T + n_tchunks - 1) / n_tchunks;
     g.n_tchunks = (p.max_T + g.TC - 1) / g.TC;
     g.gx = gx;

@@ -15,6 +15,7 @@
 // snn_lstm_backward does for H = 32.  Deterministic: no atomics, fixed summation order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
@@ -315,18 +316,21 @@ __global__ void __launch_bounds__(256, 1) bwd_rec_kernel(const Bwd2Params p, int
 template <int H, int TSW>
 __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, int n_tchunks)
 {
-    constexpr int TS = 4;   // time steps per workgroup: every W_ih^T operand load feeds TSW MFMAs
+    // the 4 waves cover min(MTX, 4) output tiles x (4 / that) groups of TSW time steps: a workgroup covers
+    // TS = TSW * 4 / min(MTX, 4) steps, and every W_ih^T operand load feeds TSW MFMAs.  Large batches take the largest
+    // TSW (fewest operand loads); small ones TSW = 1, so that the steps of a tile spread over more compute units.
     const SnnLayout& y = p.lay;
     const int dirs = y.dirs;
+    const int MTX = dirs * H / 32, MTXw = MTX < 4 ? MTX : 4;
+    const int TS = TSW * (4 / MTXw);
     const int tile = blockIdx.x / n_tchunks, tw = (blockIdx.x - tile * n_tchunks) * TS;
     const int T = p.tile_T[tile];
     if (tw >= T) return;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
-    const int MTX = dirs * H / 32;
     const int orig = p.order[tile * SNN_TILE + cl];
     const bool masked = p.mk.mode != SNN_MASK_NONE;
-    const int mt0 = TSW == TS ? w : w % MTX, mt_step = TSW == TS ? 4 : MTX * (TS / TSW);   // launch: MTX * (TS / TSW) == 4
-    const int t0 = tw + (TSW == TS ? 0 : (w / MTX) * TSW);
+    const int mt0 = w % MTXw, mt_step = MTXw;
+    const int t0 = tw + (w / MTXw) * TSW;
     for (int mt = mt0; mt < MTX; mt += mt_step) {
         f32x16 acc[TSW];
 #pragma unroll
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
             const float* B = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t0) * 4 * H * 32 + lane;
             // operands stream from L2: issue a batch of KB k-steps' loads, then their MFMAs (steps beyond the
             // tile's last one read the next step's rows of the same buffer and are never stored)
-            constexpr int KB = TSW == TS ? 16 : 32;
+            constexpr int KB = TSW == 4 ? 16 : 32;
             for (int k0 = 0; k0 < 2 * H; k0 += KB) {
                 float a[KB], b[TSW][KB];
 #pragma unroll
@@ -614,9 +618,27 @@ __global__ void __launch_bounds__(256) stream_reduce_kernel(SnnLayout y, int G, 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-struct Bwd2Geom { int n_chunks; int64_t wt_floats, dfeat_floats, dG_floats, dy_floats, slab_floats, total_bytes; };
+struct Bwd2Geom { int n_chunks, n_dG; int64_t wt_floats, dfeat_floats, dG_floats, dy_floats, slab_floats, total_bytes; };
 
-static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, int64_t* wt_hh, int64_t* wt_ih)
+// Small batch: even half tiles get a compute unit each.  The split backward then (a) runs its recurrent kernels on half
+// tiles where they exist (snn_rec16.hip), (b) spreads bwd_dx over single time steps, and (c) keeps the gate gradients of
+// EVERY layer (n_dG = L buffers instead of one) so that the weight-gradient GEMM of a layer runs on a side stream beside
+// the recurrent chain of the layer below instead of in front of it.  SNN_REC16=0|1 forces the rule off / on (A/B, tests).
+static bool small_batch(const SnnLayout& y, int n_tiles)
+{
+    const char* f16 = getenv("SNN_REC16");
+    if (f16) return f16[0] == '1';
+    static thread_local int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev != cached_dev) {
+        if (hipDeviceGetAttribute(&cached_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        cached_dev = dev;
+    }
+    return (int64_t)n_tiles * y.dirs * 2 <= cached_cus;
+}
+
+static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, int64_t* wt_hh, int64_t* wt_ih, bool small = false)
 {
     int64_t off = 0;
     for (int ld = 0; ld < y.L * y.dirs; ++ld) {
@@ -637,7 +659,8 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     // (a chunk is at least ~8 tile-steps: every chunk costs a slab of P floats that chunk_reduce_kernel reads back)
     g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, std::max<int64_t>(total / 8, std::min<int64_t>(total / 2, 16))));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
-    g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
+    g->n_dG = small ? y.L : 1;
+    g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->n_dG * g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
 }
 
 // ---- streamed path, host side
@@ -741,8 +764,30 @@ bool snn_bwd_big_supported(const SnnLayout& y)
 int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
 {
     Bwd2Geom g;
-    bwd2_geom(y, n_tiles, max_T, &g, nullptr, nullptr);
+    bwd2_geom(y, n_tiles, max_T, &g, nullptr, nullptr, small_batch(y, n_tiles));
     return g.total_bytes;
+}
+
+bool snn_rec16_supported(const SnnLayout& y);                          // snn_rec16.hip
+int snn_launch_bwd_rec16(const Bwd2Params& p, int l, hipStream_t st);
+
+// side stream + events of the overlapped weight-gradient GEMMs (small batches), one set per host thread and device
+struct SideStream { int dev = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static int side_stream(SideStream** out)
+{
+    static thread_local SideStream ss[SNN_NOALLOC_MAX_DEVICES];
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SNN_NOALLOC_MAX_DEVICES) { snn_set_error("device ordinal %d out of range", dev); return SNN_ERR_ARG; }
+    SideStream& x = ss[dev];
+    if (!x.s) {
+        HIP_CHECK(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+        x.dev = dev;
+    }
+    *out = &x;
+    return SNN_OK;
 }
 
 template <int H, int CELL>
@@ -750,23 +795,34 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
 {
     Bwd2Params p = p0;
     const SnnLayout& y = p.lay;
-    const int n_ld = y.L * y.dirs;
     launch_head_prep(p, 1, st);
     HIP_CHECK(hipGetLastError());
     constexpr int KSPLIT = 4 / (H / 32);
     const size_t lds_rec = sizeof(float) * ((size_t)4 * H * 32 + (size_t)KSPLIT * H * 32);
     HIP_CHECK(hipFuncSetAttribute((const void*)bwd_rec_kernel<H, CELL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec));
-    float* dyA = p.dfeat + g.dfeat_floats + g.dG_floats;
+    float* dG0 = p.dG;
+    float* dyA = p.dfeat + g.dfeat_floats + g.n_dG * g.dG_floats;
     float* dyB = dyA + g.dy_floats;
+    const bool small = g.n_dG > 1 || (y.L == 1 && small_batch(y, p.n_tiles));   // (see small_batch)
+    const bool rec16 = small && snn_rec16_supported(y);
+    const bool overlap = g.n_dG == y.L && y.L > 1;
+    SideStream* side = nullptr;
+    if (overlap && side_stream(&side) != SNN_OK) return SNN_ERR_HIP;
     for (int l = y.L - 1; l >= 0; --l) {
         p.dy_in = (l & 1) ? dyA : dyB;    // written by the layer above
         p.dy_out = (l & 1) ? dyB : dyA;
-        hipLaunchKernelGGL((bwd_rec_kernel<H, CELL>), dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
+        p.dG = dG0 + (overlap ? (int64_t)l * g.dG_floats : 0);
+        if (rec16) snn_launch_bwd_rec16(p, l, st);
+        else hipLaunchKernelGGL((bwd_rec_kernel<H, CELL>), dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
         HIP_CHECK(hipGetLastError());
         if (l > 0) {
-            const int n_tchunks = (p.max_T + 3) / 4;
-            const int mtx = y.dirs * H / 32;
-            auto dx = mtx == 1 ? bwd_dx_kernel<H, 1> : mtx == 2 ? bwd_dx_kernel<H, 2> : bwd_dx_kernel<H, 4>;
+            const int mtx = y.dirs * H / 32, mtxw = std::min(mtx, 4);
+            // time steps per wave: 4 * mtxw / 4 fills a 4-step workgroup (fewest operand loads); 1 for small batches
+            int tsw = mtx == 1 ? 1 : mtx == 2 ? 2 : 4;
+            if (small && mtx <= 2) tsw = 1;
+            const int ts = tsw * (4 / mtxw);
+            const int n_tchunks = (p.max_T + ts - 1) / ts;
+            auto dx = tsw == 1 ? bwd_dx_kernel<H, 1> : tsw == 2 ? bwd_dx_kernel<H, 2> : bwd_dx_kernel<H, 4>;
             hipLaunchKernelGGL(dx, dim3(p.n_tiles * n_tchunks), dim3(256), 0, st, p, l, n_tchunks);
             HIP_CHECK(hipGetLastError());
         }
@@ -775,8 +831,20 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
         if (!dw) { snn_set_error("no weight-gradient kernel for H=%d with input width %d", H, y.I[l]); return SNN_ERR_UNSUPPORTED; }
         const size_t lds_dw = sizeof(float) * ((size_t)128 * PAD + (size_t)ntn * 32 * PAD);
         HIP_CHECK(hipFuncSetAttribute((const void*)dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));
-        hipLaunchKernelGGL(dw, dim3(y.dirs * (4 * H / 128) * g.n_chunks), dim3(256), lds_dw, st, p, l, g.n_chunks);
+        // the weight gradients of layer l need only this layer's dG (kept: one buffer per layer) and the tape: on the side
+        // stream they run beside bwd_dx / the recurrent kernel of layer l - 1; the last layer's run on the main stream
+        hipStream_t dws = st;
+        if (overlap && l > 0) {
+            HIP_CHECK(hipEventRecord(side->fork, st));
+            HIP_CHECK(hipStreamWaitEvent(side->s, side->fork, 0));
+            dws = side->s;
+        }
+        hipLaunchKernelGGL(dw, dim3(y.dirs * (4 * H / 128) * g.n_chunks), dim3(256), lds_dw, dws, p, l, g.n_chunks);
         HIP_CHECK(hipGetLastError());
+    }
+    if (overlap) {      // join: everything the side stream was given precedes the reduction
+        HIP_CHECK(hipEventRecord(side->join, side->s));
+        HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
     }
     hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((y.c_head_w + 255) / 256)), dim3(256), 0, st, y.c_head_w, y.P,
                        g.n_chunks, p.slabs, p.dflat, p.accumulate);
@@ -792,7 +860,7 @@ int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* le
     Bwd2Params p;
     memset(&p, 0, sizeof(p));
     Bwd2Geom g;
-    bwd2_geom(y, n_tiles, max_T, &g, p.wt_hh, p.wt_ih);
+    bwd2_geom(y, n_tiles, max_T, &g, p.wt_hh, p.wt_ih, small_batch(y, n_tiles));
     if (workspace_bytes < g.total_bytes) {
         snn_set_error("snn_lstm_backward: workspace %lld < required %lld bytes", (long long)workspace_bytes, (long long)g.total_bytes);
         return SNN_ERR_WORKSPACE;
@@ -804,7 +872,7 @@ int snn_lstm_backward_big(const SnnLayout& y, const float* xp, const int32_t* le
     p.WT = (float*)workspace;
     p.dfeat = p.WT + g.wt_floats;
     p.dG = p.dfeat + g.dfeat_floats;
-    p.slabs = p.dG + g.dG_floats + 2 * g.dy_floats;
+    p.slabs = p.dG + g.n_dG * g.dG_floats + 2 * g.dy_floats;
     p.dflat = dflat;
     p.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;

@@ -77,6 +77,10 @@ class Config:
     def n_tensors(self):
         return 4 * self.num_layers * self.dirs + 1
 
+    def kl_terms_floats(self, n_samples):
+        """floats of snn_bbb_sample's kl_terms scratch (include/snn_hip.h)."""
+        return L.check(L.load().snn_kl_terms_floats(ctypes.byref(self.c), n_samples), "snn_kl_terms_floats")
+
     def supported(self):
         return bool(L.load().snn_supported(ctypes.byref(self.c)))
 
@@ -260,7 +264,7 @@ def bbb_sample(cfg, mu, rho, n_samples, prior, eps=None, mean_field=False, seed=
     kl = terms = None
     if want_kl:
         kl = torch.empty(n_samples, dtype=torch.float32, device=mu.device)
-        terms = torch.empty(n_samples * cfg.n_tensors * 3, dtype=torch.float32, device=mu.device)
+        terms = torch.empty(cfg.kl_terms_floats(n_samples), dtype=torch.float32, device=mu.device)
     pr = prior.c
     L.check(L.load().snn_bbb_sample(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset,
                                     n_samples, ctypes.byref(pr), _ptr(wk), _ptr(kl), _ptr(terms), _stream()),
@@ -468,7 +472,7 @@ def bbb_sample_train(cfg, mu, rho, prior, eps=None, mean_field=False, seed=0, of
             raise L.SnnError(f"eps has {eps.numel()} floats, expected {Ps}")
     wk = torch.empty(cfg.PK, dtype=torch.float32, device=mu.device)
     kl = torch.empty(1, dtype=torch.float32, device=mu.device)
-    terms = torch.empty(cfg.n_tensors * 3, dtype=torch.float32, device=mu.device)
+    terms = torch.empty(cfg.kl_terms_floats(1), dtype=torch.float32, device=mu.device)
     pr = prior.c
     L.check(L.load().snn_bbb_sample(ctypes.byref(cfg.c), _ptr(mu), _ptr(rho), _ptr(eps), mode, seed, offset, 1,
                                     ctypes.byref(pr), _ptr(wk), _ptr(kl), _ptr(terms), _stream()), "snn_bbb_sample")

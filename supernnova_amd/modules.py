@@ -156,6 +156,8 @@ class _HipRNN(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_flat_params_cache", None)   # conversions may replace Parameter objects
+        self.__dict__.pop("_flat_checked", None)
+        self.__dict__.pop("_train_state", None)
         return super()._apply(fn, *args, **kwargs)
 
     def _flatten(self):
@@ -179,17 +181,28 @@ class _HipRNN(nn.Module):
 
     def flat_parameters(self):
         """The flat buffer all parameters are views of (re-flattened if something re-pointed them)."""
-        flat = getattr(self, "_pflat", None)
+        flat = self.__dict__.get("_pflat")
         ok = flat is not None
         if ok:
-            ptr, esz = flat.data_ptr(), flat.element_size()
-            for p in self._flat_params():
-                if p.data_ptr() != ptr or p.device != flat.device:
-                    ok = False
-                    break
-                ptr += p.numel() * esz
+            # every parameter must still be the view of `flat` that _flatten made it.  Conversions (.to(), .cuda(), ...)
+            # go through _apply, which drops `_flat_checked`; between two of them the first and the last parameter are
+            # compared (a training step calls this several times: walking all 35 parameters cost 17 us per call)
+            ps = self._flat_params()
+            if self.__dict__.get("_flat_checked"):
+                ok = ps[0].data_ptr() == flat.data_ptr() and \
+                    ps[-1].data_ptr() == flat.data_ptr() + (flat.numel() - ps[-1].numel()) * flat.element_size()
+            else:
+                ptr, esz = flat.data_ptr(), flat.element_size()
+                for p in ps:
+                    if p.data_ptr() != ptr or p.device != flat.device:
+                        ok = False
+                        break
+                    ptr += p.numel() * esz
+                if ok:
+                    self.__dict__["_flat_checked"] = True
         if not ok:
             self._flatten()
+            self.__dict__["_flat_checked"] = True
         return self._pflat
 
     def _flat(self, tag):
@@ -318,6 +331,7 @@ class _HipRNN(nn.Module):
                 raise L.SnnError(f"no HIP kernel for this configuration: {cfg}")
             st = {"dev": dev, "cfgc": cfg.c, "P": cfg.P, "PK": cfg.PK, "C": cfg.nb_classes, "nt": cfg.n_tensors,
                   "xsf": cfg.x_step_floats, "io": L.SnnTrainIO(), "sizes": {}, "bufs": {},
+                  "ktf": cfg.kl_terms_floats(1) if isinstance(self, BayesianRNN) else 0,
                   "prior": self._prior.c if isinstance(self, BayesianRNN) else None}
             self.__dict__["_train_state"] = st
         flat = self.flat_parameters()
@@ -346,7 +360,7 @@ class _HipRNN(nn.Module):
             return t
         xp_floats = plan.total_steps * st["xsf"]
         n_part = lib.snn_ce_loss_partials(N)
-        poff = (4 + 3 * st["nt"] + 1) & ~1          # fp64 partials of the CE sum: 8-byte aligned
+        poff = (4 + st["ktf"] + 1) & ~1            # fp64 partials of the CE sum: 8-byte aligned
         small = torch.empty(poff + 2 * n_part, dtype=torch.float32, device=dev)   # [CE, loss, KL, -, kl_terms..., partials...]
         logits = torch.empty((N, C), dtype=torch.float32, device=dev)
         xp, wk, tape = buf("xp", xp_floats), buf("wk", st["PK"]), buf("tape", tape_floats)
@@ -402,9 +416,9 @@ class _HipRNN(nn.Module):
         L.check(lib.snn_train_step_grad(ctypes.byref(st["cfgc"]), ctypes.byref(io), E._stream()), "snn_train_step_grad")
         n_grad = (2 * P - C) if bayes else P
         optimizer.step_flat(gflat[:n_grad], mean=not dp)
-        self.last_logits = logits
+        self.__dict__["last_logits"] = logits          # (plain attributes: nn.Module.__setattr__ costs 4 us apiece)
         if bayes:
-            self.kl = small[2]
+            self.__dict__["kl"] = small[2]
             return small[1]
         return small[0]
 

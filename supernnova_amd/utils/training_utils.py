@@ -68,8 +68,8 @@ def train_step(settings, rnn, packed_tensor, target_tensor, criterion, optimizer
 def train_step_fused(settings, rnn, packed_tensor, target_tensor, optimizer, batch_size, num_batches):
     """Same step without autograd: CE and its gradient in snn_ce_loss_grad, BPTT, BBB backward with the
     KL scale known on the host, one Adam launch.  Returns the loss as a device scalar."""
-    from .. import engine as E
-    rnn.train()
+    if not rnn.training:
+        rnn.train()
     return rnn.fused_train_step(packed_tensor, target_tensor, optimizer, 1.0 / (num_batches * batch_size),
                                 global_batch=batch_size)
 

@@ -245,5 +245,7 @@ def test_vanilla_train_mode_without_grad_still_applies_dropout():
     torch.manual_seed(11)
     with torch.no_grad():
         no_grad = rnn(x).cpu().numpy()
-    assert np.array_equal(with_grad, no_grad)
+    # (equal to fp32 rounding, not bit for bit: a small batch trains on the half-tile kernels of snn_rec16.hip, whose
+    #  16x16x4 MFMAs add the recurrent products in another order than the inference kernel's 32x32x2 ones)
+    assert np.abs(with_grad - no_grad).max() < 2e-5
     assert np.abs(no_grad - ev).max() > 1e-3

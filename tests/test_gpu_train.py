@@ -322,10 +322,12 @@ def test_layerwise_training_forward_is_bit_identical_to_the_persistent_kernel(po
         xp = E.pack_x(cfg, plan, _t(x[:, :n]))
         if n == n_big:
             os.environ["SNN_NO_LAYERWISE"] = "1"          # the persistent kernel (read per call)
+        os.environ["SNN_REC16"] = "0"     # 32-curve kernels on both sides (the half-tile kernels of small batches round differently)
         try:
             logits, tape = E.lstm_forward_train(cfg, plan, xp, wk, mk())
         finally:
             os.environ.pop("SNN_NO_LAYERWISE", None)
+            os.environ.pop("SNN_REC16", None)
         dlog = torch.zeros_like(logits)
         dlog[:n_small] = torch.linspace(-1, 1, n_small * C, device=DEV).view(n_small, C)
         dflat = E.lstm_backward(cfg, plan, xp, wk, tape, dlog, mk())
@@ -631,8 +633,13 @@ def test_split_training_forward_is_bit_identical(D, H, L, bidir, pool, C, cell, 
         if masked == "step":
             return E.Masks(mode=2, which=4 | 8, dropout=0.2, seed=79, mid_T=plan.max_T)
         return None
-    plan, res, names = _forward_train_variants(cfg, n, T, masks_fn)
-    assert "fwd_gx_kernel" in names[1] and "fwd_gx_kernel" not in names[0], names
+    import os
+    os.environ["SNN_REC16"] = "0"        # the 32-curve recurrent kernels (the half-tile ones round differently: test below)
+    try:
+        plan, res, names = _forward_train_variants(cfg, n, T, masks_fn)
+    finally:
+        os.environ.pop("SNN_REC16", None)
+    assert "fwd_gx_kernel" in names[1] and "fwd_gx_kernel" not in names[0] and "rec16" not in names[1], names
     _assert_same_tape(cfg, plan, res[0], res[1])
 
 
@@ -685,3 +692,55 @@ def test_one_call_train_step_equals_the_call_by_call_sequence(model):
         out.append((rnn.flat_parameters().detach().clone(), losses))
     assert torch.equal(out[0][0], out[1][0])
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("D,H,L,bidir,pool,C,masked,n,T", [
+    (24, 32, 2, True, "mean", 2, None, 128, 40),
+    (24, 32, 2, True, "mean", 2, "locked", 100, 17),
+    (26, 32, 3, True, "standard", 3, "step", 70, 9),
+    (24, 32, 2, False, "standard", 2, None, 33, 12),
+    (42, 64, 2, True, "mean", 5, "locked", 65, 11),
+    (78, 64, 1, True, "standard", 14, None, 17, 30),
+    (24, 32, 2, True, "mean", 2, None, 1, 1),
+])
+def test_half_tile_recurrent_kernels_match_the_32_curve_kernels(D, H, L, bidir, pool, C, masked, n, T):
+    """16 curves per workgroup on v_mfma_f32_16x16x4_f32 (snn_rec16.hip), forward and backward: the same arithmetic in
+    another summation order (four products per instruction instead of two), so logits, tape and gradients agree with
+    the 32-curve kernels to fp32 rounding -- logits within LOGIT_ATOL, gradients within GRAD_RTOL of the tensor's
+    max |grad| -- not bit for bit.  (Parity against the reference: the fixture tests above run batches <= 128 curves,
+    which take these kernels by default.)"""
+    import os
+    from supernnova_amd import engine as E
+    from supernnova_amd import _lib as Lm
+    cfg = E.Config(D, H, L, bidir, C, pool)
+
+    def masks_fn(plan):
+        if masked == "locked":
+            return E.Masks(mode=2, which=1 | 2 | 4 | 8, dropout=0.1, seed=78, mid_T=1)
+        if masked == "step":
+            return E.Masks(mode=2, which=4 | 8, dropout=0.2, seed=79, mid_T=plan.max_T)
+        return None
+    res = {}
+    for r16 in ("0", "1"):
+        os.environ["SNN_REC16"] = r16
+        try:
+            plan, out, names = _forward_train_variants(cfg, n, T, masks_fn, variants=("1",))
+        finally:
+            os.environ.pop("SNN_REC16", None)
+        assert ("rec16" in names[0]) == (r16 == "1"), names
+        assert (Lm.load().snn_last_backward_path() or b"").decode() == "split"
+        res[r16] = out[0]
+    a, b = res["0"], res["1"]
+    assert float((a[0] - b[0]).abs().max()) < LOGIT_ATOL
+    Hh, n_ld = cfg.hidden_size, cfg.num_layers * cfg.dirs
+    step = 6 * Hh * 32
+    per_tile = n_ld * plan.max_T * step + cfg.F * 32
+    ta = a[1][: plan.n_tiles * per_tile].view(plan.n_tiles, per_tile)
+    tb = b[1][: plan.n_tiles * per_tile].view(plan.n_tiles, per_tile)
+    tile_T = torch.from_numpy(np.array(plan.tile_T, dtype=np.int64)).to(DEV)
+    rows_a = ta[:, : n_ld * plan.max_T * step].view(plan.n_tiles, n_ld, plan.max_T, step)
+    rows_b = tb[:, : n_ld * plan.max_T * step].view(plan.n_tiles, n_ld, plan.max_T, step)
+    live = (torch.arange(plan.max_T, device=DEV)[None, :] < tile_T[:, None])[:, None, :, None]
+    assert float((torch.where(live, rows_a, 0.0) - torch.where(live, rows_b, 0.0)).abs().max()) < 2e-5
+    assert float((ta[:, n_ld * plan.max_T * step:] - tb[:, n_ld * plan.max_T * step:]).abs().max()) < 2e-6
+    _grad_check(b[2].cpu().numpy(), a[2].cpu().numpy(), "half-tile vs 32-curve gradient")
