@@ -737,7 +737,9 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     if (e->big && !train && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)
     bool pair = false;
-    if (!train && (!masked || masks->mid_T <= 1) && !e->big && n_tiles > 1 && y.cell == 0) {   // locked masks only
+    // (also for a single tile -- a missing partner is a tile without live curves -- so that every inference launch of a
+    // shape runs the same arithmetic: the pair kernel folds the activations' exp2 factors into its weight registers)
+    if (!train && (!masked || masks->mid_T <= 1) && !e->big && y.cell == 0) {   // locked masks only
         static const bool no_pair = getenv("SNN_NO_PAIR") != nullptr;   // A/B measurements only
         fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs, masked);
         if (fp) { fn = fp; pair = true; }

@@ -50,7 +50,16 @@ __device__ __forceinline__ float lane_select(unsigned long long mask, float a, f
     return r;
 }
 
-template <int H, int KKI, int DIRS, bool FIRST, bool LAST, bool MASKED>
+// UNIFORM: every curve of both tiles runs all T steps of the pair (the usual case: curves are sorted by length, and a
+// length class of a large batch spans many tiles) -- the per-lane "still inside the curve" selects of the cell update
+// drop out (3 of ~32 vector instructions per hidden unit and step, on the pipe the fp32 MFMAs share).  Same values.
+// exp2 factor of gate block `gate` (0 i, 1 f, 2 g, 3 o), and the activations of pre-scaled arguments
+__device__ __forceinline__ float gate_exp2_scale(int gate) { return gate == 2 ? 2.88539008177792681f : -1.44269504088896341f; }
+__device__ __forceinline__ float rcp_1p_exp2(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z)); }
+__device__ __forceinline__ float sigmoid_exp2(float z) { return rcp_1p_exp2(z); }     // z = -a log2 e
+constexpr float K2 = 2.88539008177792681f;                                             // 2 log2 e
+
+template <int H, int KKI, int DIRS, bool FIRST, bool LAST, bool MASKED, bool UNIFORM>
 __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c, int l, int d, int k_A, int k_bias,
                                            int k_head_w, float* xin, float* hb, float* part, float* logit, float* bl)
 {
@@ -78,9 +87,19 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
 #pragma unroll
         for (int kk = KKI; kk < KK; ++kk) wreg[kk] = __fmul_rn(m, wreg[kk]);
     }
+    // The exp2 factor of each gate's activation goes into its weight rows and bias, once per phase: sigmoid(a) =
+    // 1 / (1 + 2^(-a log2 e)), tanh(a) = 1 - 2 / (1 + 2^(2 a log2 e)), so rows of i, f, o carry -log2 e and rows of g
+    // 2 log2 e, and the accumulator IS the exponent -- one multiplication less per activation in the step loop, on the
+    // issue pipe the fp32 MFMAs share (the cell state is carried as 2 log2 e * c for the same reason, see act_piece).
+    // One extra fp32 rounding per weight; parity bar unchanged (tests against the oracle and the reference fixtures).
+    {
+        const float sc = gate_exp2_scale((c.lane & 31) >> 3);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wreg[kk] = __fmul_rn(sc, wreg[kk]);
+    }
     if (c.cl < 16) {
         const float* B = c.wks + k_bias + (c.w * 2 + c.hf) * 16;
-        bl[(c.w * 2 + c.hf) * 16 + c.cl] = B[c.cl] + B[NW * 32 + c.cl];
+        bl[(c.w * 2 + c.hf) * 16 + c.cl] = __fmul_rn(gate_exp2_scale(c.cl >> 2), B[c.cl] + B[NW * 32 + c.cl]);
     }
     const f32x16* binit_p = reinterpret_cast<const f32x16*>(bl + (c.w * 2 + c.hf) * 16);
     const int j0 = 8 * c.w + 4 * c.hf;
@@ -169,18 +188,19 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
         // order, so the piece cannot be hoisted to the head of the chain (which the compiler otherwise does with
         // everything that only depends on the previous chain's accumulator).
         auto pin = [](float v) { asm volatile("" : "+v"(v)); return v; };
-        if (st == 0) r.ig[u] = snn_sigmoid(pin(acc[u]));
-        else if (st == 1) r.gg[u] = snn_tanh(pin(acc[8 + u]));
-        else if (st == 2) r.fg[u] = snn_sigmoid(pin(acc[4 + u]));
+        // acc holds the exp2 exponents (scaled rows); gg and the cell state are carried times K2 = 2 log2 e
+        if (st == 0) r.ig[u] = sigmoid_exp2(pin(acc[u]));
+        else if (st == 1) r.gg[u] = fmaf(-2.0f * K2, rcp_1p_exp2(pin(acc[8 + u])), K2);                   // K2 * tanh(a_g)
+        else if (st == 2) r.fg[u] = sigmoid_exp2(pin(acc[4 + u]));
         else if (st == 3) {
-            const float cn = fmaf(pin(r.fg[u]), cst[q][u], __fmul_rn(r.ig[u], r.gg[u]));   // same rounding as lstm_fwd_kernel
-            r.tc[u] = snn_tanh(cn);
-            cst[q][u] = lane_select(vmask, cn, cst[q][u]);
-        } else if (st == 4) r.og[u] = snn_sigmoid(pin(acc[12 + u]));
+            const float cn = fmaf(pin(r.fg[u]), cst[q][u], __fmul_rn(r.ig[u], r.gg[u]));                    // K2 * c_t
+            r.tc[u] = fmaf(-2.0f, rcp_1p_exp2(cn), 1.0f);                                                   // tanh(c_t)
+            cst[q][u] = UNIFORM ? cn : lane_select(vmask, cn, cst[q][u]);
+        } else if (st == 4) r.og[u] = sigmoid_exp2(pin(acc[12 + u]));
         else {
             const float hv = pin(r.og[u]) * r.tc[u];
-            hst[q][u] = lane_select(vmask, hv, hst[q][u]);
-            const float outv = lane_select(vmask, hv, 0.0f);
+            hst[q][u] = UNIFORM ? hv : lane_select(vmask, hv, hst[q][u]);
+            const float outv = UNIFORM ? hv : lane_select(vmask, hv, 0.0f);
             hb[q * HB + (j0 + u) * 32 + c.cl] = hst[q][u];
             if (last_layer) hsum[q][u] += outv;
             else yout[q][(int64_t)t * HB + (j0 + u) * 32 + c.cl] = MASKED ? __fmul_rn(mmid[q][u], outv) : outv;
@@ -349,18 +369,26 @@ __global__ void __launch_bounds__(H * 8, MASKED ? SNN_PAIR_MASKED_WAVES : SNN_PA
         for (int idx = c.tid; idx < 2 * y.C * 32; idx += NT) logit[idx] = 0.0f;
         __syncthreads();
 
+        // all 64 curves as long as the pair's first one (lengths are sorted, descending): the UNIFORM instantiation
+        const bool uniform = has1 && __builtin_amdgcn_readfirstlane(p.len_sorted[c.tile[1] * SNN_TILE + SNN_TILE - 1]) == c.T;
         for (int l = 0; l < y.L; ++l) {
             const bool last = l == y.L - 1;
             for (int d = 0; d < DIRS; ++d) {
+#define SNN_PAIR_PHASE(KKI_, FIRST_, LAST_)                                                                                   \
+    do {                                                                                                                      \
+        if (uniform) pair_phase<H, KKI_, DIRS, FIRST_, LAST_, MASKED, true>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);  \
+        else pair_phase<H, KKI_, DIRS, FIRST_, LAST_, MASKED, false>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);         \
+    } while (0)
                 if (l == 0) {
                     const int kA = d * BLK0, kB = kA + NW * (KKI0 + H / 2) * 64;
-                    if (last) pair_phase<H, KKI0, DIRS, true, true, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
-                    else pair_phase<H, KKI0, DIRS, true, false, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    if (last) SNN_PAIR_PHASE(KKI0, true, true);
+                    else SNN_PAIR_PHASE(KKI0, true, false);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1, kB = kA + NW * (KKI1 + H / 2) * 64;
-                    if (last) pair_phase<H, KKI1, DIRS, false, true, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
-                    else pair_phase<H, KKI1, DIRS, false, false, MASKED>(p, c, l, d, kA, kB, k_head_w, xin, hb, part, logit, bl);
+                    if (last) SNN_PAIR_PHASE(KKI1, false, true);
+                    else SNN_PAIR_PHASE(KKI1, false, false);
                 }
+#undef SNN_PAIR_PHASE
             }
         }
 
