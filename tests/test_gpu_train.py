@@ -744,3 +744,47 @@ def test_half_tile_recurrent_kernels_match_the_32_curve_kernels(D, H, L, bidir, 
     assert float((torch.where(live, rows_a, 0.0) - torch.where(live, rows_b, 0.0)).abs().max()) < 2e-5
     assert float((ta[:, n_ld * plan.max_T * step:] - tb[:, n_ld * plan.max_T * step:]).abs().max()) < 2e-6
     _grad_check(b[2].cpu().numpy(), a[2].cpu().numpy(), "half-tile vs 32-curve gradient")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("tag", ["t13", "t300"])
+def test_train_step_at_the_elasticc_shape_vs_reference(tag, fused):
+    """BayesianRNN train step at H=128, D=78, C=14 (BASELINE configs[4]) against the reference's own step
+    (fixtures g13, tools/make_golden.py: 20 short curves; 6 curves of up to 300 steps): loss, KL, every parameter
+    gradient (at every 8th element of the large tensors, plus each tensor's sum and L2 norm) and the parameters after
+    the Adam step.  The module is built from the reference's seed and draws its eps with the reference's calls."""
+    from test_host_logic import settings
+    from supernnova_amd.utils import training_utils as tu
+    g = load_golden(f"g13_train_h128_{tag}")
+    st = settings(model="bayesian", hidden_dim=128, nb_classes=14, use_cuda=True)
+    torch.manual_seed(131)
+    rnn = tu.get_model(st, 78).to(DEV)
+    rnn.draws = "host"
+    opt = tu.get_optimizer(st, rnn)
+    lengths = g["lengths"].astype(np.int64)
+    packed = pack_padded_sequence(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(lengths))
+    target = torch.from_numpy(g["target"]).to(DEV)
+    B, nb = int(g["batch_size"]), int(g["num_batches"])
+    names = [str(n) for n in g["names"]]
+    params = dict(rnn.named_parameters())
+    assert list(params) == names
+    torch.manual_seed(4000)
+    if fused:
+        loss = tu.train_step_fused(st, rnn, packed, target, opt, B, nb)
+    else:
+        loss = tu.train_step(st, rnn, packed, target, torch.nn.CrossEntropyLoss(), opt, B, nb)
+    loss = float(loss.detach())
+    assert abs(loss - float(g["loss"])) < 3e-6 * abs(float(g["loss"])), (loss, float(g["loss"]))
+    assert abs(float(rnn.kl.detach()) - float(g["kl"])) < 1e-5 * abs(float(g["kl"]))
+    sub = lambda a: a.reshape(-1) if a.size <= 4096 else a.reshape(-1)[::8]
+    for i, n in enumerate(names):
+        gref, (gsum, gl2, gmax) = g[f"g{i}"], g[f"gstat{i}"]
+        if not fused:
+            got = params[n].grad.detach().cpu().numpy().astype(np.float64)
+            assert np.abs(sub(got) - gref).max() < GRAD_RTOL * max(gmax, 1e-12), n
+            assert abs(np.sqrt((got ** 2).sum()) - gl2) < GRAD_RTOL * max(gl2, 1e-12), n
+            assert abs(got.sum() - gsum) < GRAD_RTOL * max(gl2 * np.sqrt(got.size), 1e-12), n
+        # Adam's first step moves every parameter by lr * g / (|g| + eps): compare where the gradient is not rounding noise
+        p1 = sub(params[n].detach().cpu().numpy())
+        live = np.abs(gref) > 1e-3 * gmax
+        assert np.abs(p1 - g[f"p{i}"])[live].max() < 2e-6, n

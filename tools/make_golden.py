@@ -439,6 +439,43 @@ def g4_train():
         save(f"g4_train_{model}", **arrs)
 
 
+# ---------------------------------------------------------------- G13 train steps at the configs[4] shape
+def _subsample(a):
+    """Every 8th element of a large tensor (all of a small one): keeps a 1.2 M-parameter fixture at a few hundred KB."""
+    a = np.asarray(a).reshape(-1)
+    return a if a.size <= 4096 else a[::8]
+
+
+def g13_train_elasticc():
+    """BayesianRNN train step (utils/training_utils.py:508-525) at H=128, D=78 (6 filters + redshift), C=14 -- the shape
+    BASELINE configs[4] trains at -- for a short batch and for a batch with 300-step curves.  The model is built from
+    a seed (the package's modules reproduce the reference's seeded initial values: fixture g0), eps are the reference's
+    own draws after torch.manual_seed(4000) (the package's host_eps makes the same calls in the same order), so the
+    fixture holds inputs, loss, logits and -- per parameter tensor -- the gradient and the Adam-updated values at every
+    8th element plus the tensor's sum and L2 norm."""
+    D, C, H = 78, 14, 128
+    for tag, T, lengths in (("t13", 13, None), ("t300", 300, [300, 300, 257, 120, 33, 3])):
+        B = 20 if lengths is None else len(lengths)
+        st = settings(hidden_dim=H, nb_classes=C)
+        torch.manual_seed(131)
+        m = build(bayesian_rnn.BayesianRNN, D, st)
+        x, lens = make_batch(132, T, B, D, lengths)
+        target = np.random.default_rng(133).integers(0, C, size=B).astype(np.int64)
+        packed = pack_padded_sequence(torch.from_numpy(x), torch.from_numpy(lens))
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        torch.manual_seed(4000)
+        loss, grads, out = ref_train_step(m, packed, torch.from_numpy(target), opt, B, 7, True)
+        arrs = dict(x=x, lengths=lens, target=target, num_batches=np.int64(7), batch_size=np.int64(B), lr=np.float64(1e-3),
+                    loss=np.float64(loss), logits=out, kl=np.float64(float(m.kl)), names=np.array(list(grads.keys())))
+        sd1 = sd_np(m)
+        for i, (n, gr) in enumerate(grads.items()):
+            arrs[f"g{i}"] = _subsample(gr)
+            arrs[f"gstat{i}"] = np.array([gr.astype(np.float64).sum(), np.sqrt((gr.astype(np.float64) ** 2).sum()), np.abs(gr).max()])
+            arrs[f"p{i}"] = _subsample(sd1[n])
+        save(f"g13_train_h128_{tag}", **arrs)
+        print(f"g13 {tag}: loss {loss:.6f}, {len(grads)} tensors")
+
+
 # ---------------------------------------------------------------- G12 GRU / tanh-RNN train steps
 def g12_train_cells():
     """VanillaRNN with layer_type gru / rnn (vanilla_rnn.py:26-32 -> torch.nn.GRU / torch.nn.RNN) through the reference's
@@ -965,6 +1002,8 @@ if __name__ == "__main__":
         g11_loader()
     if "g12" in which:
         g12_train_cells()
+    if "g13" in which:
+        g13_train_elasticc()
     if "g8" in which:
         g8_swag()
     if "g9" in which:
