@@ -79,9 +79,11 @@ def bayes_init(cfg, seed, device):
 
 
 def flops_per_pass(cfg, lengths_sum, n_curves, S):
-    """per curve per sample l*16H(D+4H) + 4HC (L=2, bidirectional)."""
+    """per curve per sample l*16H(D+4H) + 4HC (L=2, bidirectional); a GRU has 3 gates' rows and a tanh RNN 1
+    where the LSTM has 4 (algorithmic FLOPs: rows the kernels pad to a full MFMA tile are not counted)."""
     H, D, C = cfg.hidden_size, cfg.input_size, cfg.nb_classes
-    return S * (lengths_sum * 16 * H * (D + 4 * H) + n_curves * 4 * H * C)
+    ng = {"lstm": 4, "gru": 3, "rnn": 1}[cfg.cell]
+    return S * (lengths_sum * 4 * ng * H * (D + 4 * H) + n_curves * 4 * H * C)
 
 
 def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves, model="bayesian"):
@@ -205,16 +207,23 @@ def run(args, rank, world, dev, backend, dist):
 
     big = args.workload == "elasticc"
     var = args.workload == "variational"
+    plain = args.workload in ("gru", "rnn")      # VanillaRNN with settings.layer_type gru / rnn: one deterministic forward
     if var and args.precision == "bf16x3":
         raise SystemExit("the masked (variational) kernels are f32 and f16x2 only")
+    if plain and args.precision != "f32":
+        raise SystemExit("the gru / rnn cells are f32 only")
     if big:
         cfg = E.Config(78, 128, 2, True, 14, "mean")
         if args.curves == 1_250_000:
             args.curves = 8192
         if args.max_len == 40:
             args.max_len = 300
+    elif plain:
+        cfg = E.Config(24, 32, 2, True, 2, "mean", cell=args.workload)
+        if args.samples == 50:
+            args.samples = 1          # (validate_rnn.py:528-529: a VanillaRNN is classified with one forward)
     else:
-        cfg = E.Config(24, 32, 2, True, 2, "mean")
+        cfg = E.Config(24, 64 if args.workload == "h64" else 32, 2, True, 2, "mean")
     cfg = cfg.with_precision(args.precision)
     S, N = args.samples, args.curves
     mu, rho = bayes_init(cfg, 0, dev)
@@ -223,7 +232,7 @@ def run(args, rank, world, dev, backend, dist):
         lengths.fill_(args.max_len)      # exactly 300 steps for config 5
     lengths_host = lengths.cpu().numpy()
     prior = E.Prior()
-    if var:   # torch.nn.LSTM default init U(+-1/sqrt(H)); one weight image shared by all samples
+    if var or plain:   # torch.nn.LSTM / GRU / RNN default init U(+-1/sqrt(H)); one weight image shared by all samples
         gw = torch.Generator(device="cpu")
         gw.manual_seed(0)
         k = 1.0 / np.sqrt(cfg.hidden_size)
@@ -252,7 +261,9 @@ def run(args, rank, world, dev, backend, dist):
     def step(i, timed):
         plan = E.Plan(cfg, lengths_host, dev)
         xp = E.pack_x(cfg, plan, x)
-        if var:
+        if plain:
+            wk, kl, masks = w_var, torch.zeros(1, device=dev), None
+        elif var:
             wk, kl = w_var, torch.zeros(1, device=dev)
             masks = E.Masks(mode=2, which=0xF, dropout=0.05, seed=1234, offset=i * S)
         else:
@@ -267,7 +278,11 @@ def run(args, rank, world, dev, backend, dist):
             dispatched[0] = E.last_forward_kernel()
         # the only exchange of the inference path: per-curve mean / std over the S draws, (N_local, 2C),
         # reduced on the device and gathered to rank 0 -- inside the timed region
-        std, mean = torch.std_mean(probs, dim=1, unbiased=True)
+        if S > 1:
+            std, mean = torch.std_mean(probs, dim=1, unbiased=True)
+        else:
+            mean = probs[:, 0]
+            std = torch.zeros_like(mean)
         gathered = Dist.gather_predictions(torch.cat([mean, std], dim=1), world * N)
         if timed:
             evs[i - args.warmup][2].record()
@@ -309,7 +324,9 @@ def run(args, rank, world, dev, backend, dist):
         splan = E.Plan(cfg, lengths_host[sub.numpy()], dev)
         sxp = E.pack_x(cfg, splan, x[:, sub_d].contiguous())
         i_last = args.warmup + args.steps - 1
-        if var:
+        if plain:
+            swk, smasks = w_var, None
+        elif var:
             swk, smasks = w_var, E.Masks(mode=2, which=0xF, dropout=0.05, seed=1234, offset=i_last * S)
             # (per-curve Philox masks are keyed by the curve index, which changes in the subset: compare shapes only)
         else:
@@ -342,17 +359,20 @@ def run(args, rank, world, dev, backend, dist):
             achieved_f32eq, achieved = achieved, fl_exec / (k_ms * 1e-3) / 1e12
             peak = PEAK_BF16_MFMA_TFLOPS
         # PMC bytes per launch of this workload: NOT measured in this run -- read from the committed rocprofv3 passes
+        # (profiles/r3/traffic.json: one entry per workload, written by microbench/traffic_json.py from the passes of
+        # microbench/profile_round3.sh; an entry counts only for the kernel and the sizes it was measured on)
         traffic = traffic_src = None
-        for rnd in ("r2", "r1"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
-                if tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and not b3 and not var:
-                    traffic, traffic_src = tj["traffic_bytes_per_launch"], f"profiles/{rnd}/traffic.json (rocprofv3 --pmc passes, not this run)"
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic.json")))["workloads"][args.workload]
+            if (tj["workload"] == {"curves_per_gpu": N, "samples": S, "max_len": args.max_len} and
+                    tj["precision"] == args.precision and tj["kernel"].split(" grid=")[0] == kname.split(" grid=")[0]):
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "profiles/r3/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": ("light curves/s classified, VariationalRNN 50 MC samples" if var else
+                       f"light curves/s classified, VanillaRNN ({args.workload.upper()} cells)" if plain else
                        "light curves/s classified, BayesianRNN 50 MC samples"),
             "value": value, "unit": "light curves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
@@ -365,10 +385,13 @@ def run(args, rank, world, dev, backend, dist):
                                    ("VariationalRNN (MC dropout p=0.05, Philox masks) LSTM 32x2 bidirectional, mean "
                                     f"pooling, D=24 (4 filters), C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU (configs[1])") if var else
-                                   ("BayesianRNN (BBB) LSTM 32x2 bidirectional, mean pooling, D=24 (4 filters), "
+                                   (f"VanillaRNN, layer_type={args.workload} (training/vanilla_rnn.py:26-32), 32x2 bidirectional, "
+                                    f"mean pooling, D=24 (4 filters), C=2, {S} forward per curve, lengths U{{3..{args.max_len}}}, "
+                                    f"{N} light curves per GPU") if plain else
+                                   (f"BayesianRNN (BBB) LSTM {cfg.hidden_size}x2 bidirectional, mean pooling, D=24 (4 filters), "
                                     f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
-                       "curves_per_gpu": N, "samples": S, "parallelism": f"shard{world}"},
+                       "curves_per_gpu": N, "samples": S, "max_len": args.max_len, "parallelism": f"shard{world}"},
             "gather": {"what": "per-curve mean and std over the S draws, (N_local, 2C) fp32, reduced on the device and "
                                "gathered to rank 0 (the path's only exchange; inside the timed region)",
                        "bytes_per_rank": N * 2 * cfg.nb_classes * 4, "ms_per_step": float(np.mean(gather_ms)),
@@ -380,7 +403,8 @@ def run(args, rank, world, dev, backend, dist):
         }
         if b3:
             out["roofline"]["fp32_equivalent_tflops"] = achieved_f32eq   # algorithmic FLOPs / kernel time
-        if world == 1 and not b3 and not big and not var and not args.no_fast_path:
+        des = args.workload == "des"
+        if world == 1 and not b3 and des and not args.no_fast_path:
             # the opt-in split-precision path on the same inputs (same parity bar): one warm-up + `steps` passes
             fcfg = cfg.with_precision("f16x2")
             fevs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps + 1)]
@@ -405,11 +429,11 @@ def run(args, rank, world, dev, backend, dist):
                                 "kernel": E.last_forward_kernel(), "kernel_ms": float(np.mean(fk)),
                                 "fp32_equivalent_tflops": fl / (float(np.mean(fk)) * 1e-3) / 1e12}
             del fxp, fwk, fprobs
-        if world == 1 and not b3 and not big and not var and not args.no_end_to_end:
+        if world == 1 and not b3 and des and not args.no_end_to_end:
             out["end_to_end"] = end_to_end(E, cfg, x, lengths, lengths_host, mu, rho, prior, S, args.steps, dev)
         if args.cpu_full and world == 1:
             out["cpu_baseline_full"] = cpu_baseline_full(cfg, x, lengths_host, mu, rho, S)
-        if args.cpu_curves > 0 and world == 1:
+        if args.cpu_curves > 0 and world == 1 and not plain:     # (the stock-PyTorch port under oracle/ times the LSTM models)
             n_cpu = min(args.cpu_curves, N)
             if big and args.cpu_curves == 3840:
                 n_cpu = 128       # one reference batch: 300 steps at H=128 x 50 forwards is already tens of seconds of CPU work
@@ -444,11 +468,12 @@ def main():
     ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--max-len", type=int, default=40)
-    ap.add_argument("--workload", choices=["des", "elasticc", "variational"], default="des",
+    ap.add_argument("--workload", choices=["des", "elasticc", "variational", "h64", "gru", "rnn"], default="des",
                     help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
                          "(H=128, 6 filters + redshift, 14 classes, 300-step sequences); variational: configs[1] "
-                         "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des) -- the last two "
-                         "are secondary measurements")
+                         "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des); h64: des with "
+                         "hidden_dim 64; gru / rnn: VanillaRNN with settings.layer_type gru / rnn, one forward per curve "
+                         "-- all but des are secondary measurements")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-selfcheck", action="store_true",
                     help="skip the subset re-run after the timed region (profiling runs: keeps the kernel statistics to "
@@ -459,7 +484,7 @@ def main():
                     help="also time the CPU port with the BASELINE.md 3 protocol (12 800 curves, median of 3, and 1 thread): "
                          "several minutes of CPU work")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the two secondary workloads (variational, elasticc) the default run appends as `secondary`")
+                    help="skip the secondary workloads (variational, elasticc, h64, gru, rnn) the default run appends as `secondary`")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the training measurements (BASELINE configs[3]) the default run appends as secondary.train "
                          "and a --gpus N run as train_dp")
@@ -500,9 +525,11 @@ def main():
         # ELAsTiCC-like H = 128 / 300-step model), two timed steps each, so that the line the driver records carries them
         import copy
         out["secondary"] = {}
-        for wl in ("variational", "elasticc"):
+        for wl in ("variational", "elasticc", "h64", "gru", "rnn"):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_curves = wl, 2, 1, 0
+            if wl == "h64":
+                a2.curves = args.curves // 4      # (an H=64 pass over 1.25 M curves is ~3 s; a quarter keeps the default run short)
             a2.no_fast_path = a2.no_end_to_end = a2.no_selfcheck = True
             a2.cpu_full = False
             sub = run(a2, rank, world, dev, backend, None)
