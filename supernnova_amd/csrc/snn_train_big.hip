@@ -380,8 +380,11 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
 // and accumulators for the widest layer, every MFMA of the loop sat behind a branch and the compiler kept the
 // accumulators in scratch memory (2.3 KB per lane at H = 128: 857 scratch instructions per tile-step, 4.8 ms per
 // layer for 128 curves x 300 steps -- 20 x the MFMA time).  One instantiation per (H, NTN) that occurs.
-template <int H, int NTN>
-__global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int l, int n_chunks)
+// OCC = workgroups per compute unit: 2 while the accumulators leave room (<= 7 column tiles; H=64 layer 1 14.6 against
+// 15.6 ms per step at 65 536 curves).  Double-buffered LDS images (one barrier per tile-step) measured the same as
+// single ones at either occupancy and are not kept.
+template <int H, int NTN, int OCC>
+__global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, int l, int n_chunks)
 {
     constexpr int MG = 4 * H / 128;   // groups of 128 gate rows (one 32-row tile per wave)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -403,20 +406,27 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
 
-    const int64_t total = (int64_t)p.n_tiles * p.max_T, per = (total + n_chunks - 1) / n_chunks;
-    const int64_t p0 = chunk * per, p1 = std::min<int64_t>(total, p0 + per);
+    // A chunk is an equal share of the VALID tile-steps (tile_off is their running count times the packed x step: tiles
+    // are sorted by length, so equal shares of the (tile, t < max_T) grid gave the chunks of the long tiles twice the
+    // mean work and the kernel ran at the pace of those).
+    const int64_t xsf = (int64_t)y.Dp * SNN_TILE;
+    const int64_t total = p.tile_off[p.n_tiles] / xsf, per = (total + n_chunks - 1) / n_chunks;
+    const int64_t v0 = std::min<int64_t>(total, chunk * per), v1 = std::min<int64_t>(total, v0 + per);
+    int n_left = (int)(v1 - v0);
+    int tile = 0, t = 0;
+    if (n_left > 0) {      // the tile that holds valid step v0: the last one whose running count is <= v0
+        int lo = 0, hi = p.n_tiles - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (p.tile_off[mid] <= v0 * xsf) lo = mid; else hi = mid - 1;
+        }
+        tile = lo;
+        t = (int)(v0 - p.tile_off[lo] / xsf);
+    }
     // Software pipeline over the chunk's tile-steps: the operands of the next tile-step are fetched into registers
     // while the MFMAs of the current one run from LDS (an un-overlapped fetch was ~60 % of the kernel's time).
     f32x4 gv[4], xv[NTN];   // 128 dG rows and NTN * 32 [h_prev | x_t | 1 | 0] rows, 8 float4 per row, 256 threads
-    auto next_valid = [&](int64_t pp) __attribute__((always_inline)) {   // first tile-step >= pp inside its tile's length (p1 if none)
-        for (; pp < p1; ++pp) {
-            const int tile = (int)(pp / p.max_T), t = (int)(pp - (int64_t)tile * p.max_T);
-            if (t < p.tile_T[tile]) break;
-        }
-        return pp;
-    };
-    auto fetch = [&](int64_t pp) __attribute__((always_inline)) {
-        const int tile = (int)(pp / p.max_T), t = (int)(pp - (int64_t)tile * p.max_T);
+    auto fetch = [&](int tile, int t) __attribute__((always_inline)) {
         const int T = p.tile_T[tile];
         const float* tape = p.tape + (int64_t)tile * p.tape_tile;
         const float* src = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t) * 4 * H * 32 + (int64_t)mg * 128 * 32;
@@ -476,26 +486,28 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
             for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = xv[i][e];
         }
     };
-    int64_t pp = next_valid(p0);
-    if (pp < p1) {
-        fetch(pp);
+    if (n_left > 0) {
+        fetch(tile, t);
         commit();
     }
     __syncthreads();
-    while (pp < p1) {
-        const int64_t np = next_valid(pp + 1);
-        if (np < p1) fetch(np);
+    while (n_left > 0) {
+        const bool more = n_left > 1;
+        if (++t >= p.tile_T[tile]) { ++tile; t = 0; }      // (more => this is a tile-step of the chunk)
+        if (more) fetch(tile, t);
+        const float* dGc = dGs + (32 * w + cl) * PAD + hf;
+        const float* xhc = xhs + cl * PAD + hf;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const float a = dGs[(32 * w + cl) * PAD + 2 * kk + hf];
+            const float a = dGc[2 * kk];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhs[(32 * nt + cl) * PAD + 2 * kk + hf], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhc[32 * nt * PAD + 2 * kk], acc[nt], 0, 0, 0);
         }
         __syncthreads();
-        if (np < p1) commit();
+        if (more) commit();
         __syncthreads();
-        pp = np;
+        --n_left;
     }
 
     // this lane's 16 gate rows: image row -> canonical row of the hidden-side (w_hh, b_hh) / input-side (w_ih, b_ih)
@@ -536,11 +548,17 @@ __global__ void __launch_bounds__(256, 1) bwd_dw_kernel(const Bwd2Params p, int 
 
 // one instantiation per column-tile count that occurs for the hidden size (layer 0: D <= 78; layer >= 1: I = H or 2H)
 typedef void (*bwd_dw_t)(const Bwd2Params, int, int);
+template <int H, int N>
+static bwd_dw_t dw_pick()
+{
+    if constexpr (N <= 7) return bwd_dw_kernel<H, N, 2>;
+    else return bwd_dw_kernel<H, N, 1>;
+}
 template <int H>
 static bwd_dw_t dw_kernel(int ntn)
 {
     switch (ntn) {
-#define SNN_DW(N) case N: if constexpr (32 * (N) >= H + 2 && 32 * ((N) - 1) < H + 2 * H + 1) return bwd_dw_kernel<H, N>; else return nullptr;
+#define SNN_DW(N) case N: if constexpr (32 * (N) >= H + 2 && 32 * ((N) - 1) < H + 2 * H + 1) return dw_pick<H, N>(); else return nullptr;
         SNN_DW(2) SNN_DW(3) SNN_DW(4) SNN_DW(5) SNN_DW(6) SNN_DW(7) SNN_DW(8) SNN_DW(9) SNN_DW(10) SNN_DW(11) SNN_DW(12) SNN_DW(13)
 #undef SNN_DW
     }
@@ -654,10 +672,16 @@ static void bwd2_geom(const SnnLayout& y, int n_tiles, int max_T, Bwd2Geom* g, i
     g->dy_floats = (int64_t)n_tiles * y.dirs * max_T * y.H * 32;
     const int64_t total = (int64_t)n_tiles * max_T;
     // weight-gradient partial sums: one slab of P floats per chunk of tile-steps; up to 256 chunks while the slabs stay
-    // under 64 MB (small models, large batches), never fewer than the 64 the large models ran with
-    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(256, ((int64_t)64 << 20) / ((int64_t)sizeof(float) * y.P)));
+    // under 96 MB (small models, large batches), never fewer than the 64 the large models ran with
+    const int64_t cap = std::max<int64_t>(64, std::min<int64_t>(256, ((int64_t)96 << 20) / ((int64_t)sizeof(float) * y.P)));
     // (a chunk is at least ~8 tile-steps: every chunk costs a slab of P floats that chunk_reduce_kernel reads back)
     g->n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(cap, std::max<int64_t>(total / 8, std::min<int64_t>(total / 2, 16))));
+    // chunks are equal shares of the work, so the grid (dirs x row groups x chunks) should come in whole rounds of the
+    // chip's workgroup slots: 256 compute units x 2 (this geometry is also the workspace size, so it is not asked of
+    // the device; on another part the rounding is merely not the best one)
+    const int unit = std::max(1, 512 / (y.dirs * std::max(1, 4 * y.H / 128)));
+    if (g->n_chunks > unit) g->n_chunks -= g->n_chunks % unit;
+    if (const char* e = getenv("SNN_DW_CHUNKS")) g->n_chunks = std::max(1, atoi(e));
     g->slab_floats = (int64_t)g->n_chunks * y.P;
     g->n_dG = small ? y.L : 1;
     g->total_bytes = (int64_t)sizeof(float) * (g->wt_floats + g->dfeat_floats + g->n_dG * g->dG_floats + 2 * g->dy_floats + g->slab_floats) + 1024;
