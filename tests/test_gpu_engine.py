@@ -215,10 +215,11 @@ def test_h128_two_pass_kernel_vs_oracle(D, C, pool, N, T):
                                             (24, 3, "mean", 1, 64, 9), (24, 2, "standard", 3, 131, 23),
                                             (24, 2, "mean", 2, 33, 1)])
 def test_paired_tile_kernel_matches_single_tile_kernel_and_oracle(D, C, pool, L, N, T):
-    """Un-masked inference over more than one tile runs the two-tiles-per-workgroup pipeline
-    (snn_forward_pair.hip); a batch of <= 32 curves runs lstm_fwd_kernel.  The same curves must give
-    bit-identical results through both (odd tile counts, partners of different length, 1..3 layers, both
-    poolings), and both must match the oracle."""
+    """H=32 bidirectional inference runs the two-tiles-per-workgroup pipeline (snn_forward_pair.hip) at every size: a
+    batch of <= 32 curves as a tile with an empty partner, pairs of equally long curves through its UNIFORM
+    instantiation.  The same curves must give bit-identical results whichever partner, position and instantiation they
+    meet (odd tile counts, partners of different length, 1..3 layers, both poolings), and must match the oracle (which
+    is what ties the pair kernel, with its exp2 factors folded into the weights, to the reference)."""
     E = _eng()
     H, S = 32, 2
     cfg = E.Config(D, H, L, True, C, pool)
@@ -452,9 +453,10 @@ def test_gru_rnn_cells_refuse_what_they_do_not_implement():
 
 @pytest.mark.parametrize("D,C,pool,L,N,T", [(24, 2, "mean", 2, 97, 17), (26, 3, "standard", 3, 64, 9), (24, 2, "mean", 1, 40, 12)])
 def test_masked_paired_tile_kernel_matches_single_tile_kernel_and_oracle(D, C, pool, L, N, T):
-    """Locked variational masks over more than one tile run the MASKED two-tiles-per-workgroup kernel; <= 32 curves run
-    lstm_fwd_kernel<MASKED>.  Same curves, same mask values: bit-identical results through both, and both match the
-    oracle; Philox masks (keyed by curve index) give the same bits in a 32-curve and in a multi-tile launch."""
+    """Locked variational masks run the MASKED two-tiles-per-workgroup kernel at every size (<= 32 curves: a tile with an
+    empty partner).  Same curves, same mask values: bit-identical results in a multi-tile launch and in launches of one
+    tile each, and both match the oracle; Philox masks (keyed by curve index) give the same bits in a 32-curve and in a
+    multi-tile launch."""
     E = _eng()
     H, S, p = 32, 3, 0.15
     cfg = E.Config(D, H, L, True, C, pool)
