@@ -259,36 +259,44 @@ __global__ void __launch_bounds__(64) kl_finish_kernel(int n_tensors, int S, snn
 // Head of the per-layer training forward (lstm_fwd_train_layer_kernel): per curve, the per-wave partial logits of the
 // phases that feed the head, added in the persistent kernel's order ((l, d) outer, wave inner, from 0.0f), then bias
 // (+ softmax): the same fp32 additions, so the same bits.
-__global__ void __launch_bounds__(64) head_combine_kernel(const FwdParams p, int NW, int dirs, int64_t k_head_b,
-                                                         const float* __restrict__ head_part)
+__global__ void __launch_bounds__(256) head_combine_kernel(const FwdParams p, int NW, int dirs, int64_t k_head_b,
+                                                          const float* __restrict__ head_part)
 {
-    const int tile = blockIdx.x, cl = threadIdx.x;
-    if (cl >= 32) return;
+    // 8 groups of 32 threads: group qs sums the partials of classes qs, qs + 8, ... (loads four at a time, additions in
+    // the fixed order ld, then wave: what the persistent kernel's in-LDS reduction does), then the first group applies
+    // the softmax.  One thread per curve doing all of it was 107 us at C = 14 with 16 partials per phase.
+    extern __shared__ float lgs[];      // [C][32]
+    const int tile = blockIdx.x, cl = threadIdx.x & 31, qs = threadIdx.x >> 5;
     const int orig = p.order[tile * SNN_TILE + cl];
-    if (orig < 0) return;
     const int n_ld = p.L * dirs;     // NW: per-wave partials per phase (H / 8 waves; 4 in the H = 128 kernels)
     const float* bo = p.wk + k_head_b;
+    for (int q = qs; q < p.C; q += 8) {
+        float a = 0.0f;
+        for (int ld = (p.pool == SNN_POOL_STANDARD ? 0 : n_ld - dirs); ld < n_ld; ++ld) {
+            const float* pp = head_part + ((int64_t)tile * n_ld + ld) * (NW * p.C * 32) + q * 32 + cl;
+            int w = 0;
+            for (; w + 4 <= NW; w += 4) {
+                const float v0 = pp[(int64_t)w * p.C * 32], v1 = pp[(int64_t)(w + 1) * p.C * 32];
+                const float v2 = pp[(int64_t)(w + 2) * p.C * 32], v3 = pp[(int64_t)(w + 3) * p.C * 32];
+                a += v0; a += v1; a += v2; a += v3;
+            }
+            for (; w < NW; ++w) a += pp[(int64_t)w * p.C * 32];
+        }
+        lgs[q * 32 + cl] = a + bo[q];
+    }
+    __syncthreads();
+    if (qs != 0 || orig < 0) return;
     const int64_t o = (int64_t)orig * p.os_n;
     float mx = -INFINITY;
-    for (int pass = 0; pass < 2; ++pass) {   // pass 0: logits + max; pass 1: probabilities (only when asked for)
-        float z = 0.0f;
-        if (pass == 1) {
-            if (!p.out_probs) break;
-            for (int q = 0; q < p.C; ++q) z += expf(p.out_probs[o + q] - mx);
-        }
-        for (int q = 0; q < p.C; ++q) {
-            if (pass == 1) { p.out_probs[o + q] = __fdiv_rn(expf(p.out_probs[o + q] - mx), z); continue; }
-            float a = 0.0f;
-            for (int ld = (p.pool == SNN_POOL_STANDARD ? 0 : n_ld - dirs); ld < n_ld; ++ld) {
-                const float* pp = head_part + ((int64_t)tile * n_ld + ld) * (NW * p.C * 32) + q * 32 + cl;
-                for (int w = 0; w < NW; ++w) a += pp[(int64_t)w * p.C * 32];
-            }
-            const float lg = a + bo[q];
-            mx = fmaxf(mx, lg);
-            if (p.out_logits) p.out_logits[o + q] = lg;
-            if (p.out_probs) p.out_probs[o + q] = lg;   // parked; normalised in pass 1
-        }
+    for (int q = 0; q < p.C; ++q) {
+        const float lg = lgs[q * 32 + cl];
+        mx = fmaxf(mx, lg);
+        if (p.out_logits) p.out_logits[o + q] = lg;
     }
+    if (!p.out_probs) return;
+    float z = 0.0f;
+    for (int q = 0; q < p.C; ++q) z += expf(lgs[q * 32 + cl] - mx);
+    for (int q = 0; q < p.C; ++q) p.out_probs[o + q] = __fdiv_rn(expf(lgs[q * 32 + cl] - mx), z);
 }
 
 // ============================================================================
@@ -309,7 +317,7 @@ fwd_rec_kernel_t snn_big_rec_kernel(int H, int KKI0, int dirs);   // snn_forward
 bool snn_gx_supported(const SnnLayout& y);
 int64_t snn_gx_floats(const SnnLayout& y, int n_tiles, int max_T);
 int snn_launch_gx(const SnnLayout& y, const FwdParams& p, int l, float* gx, int cus, hipStream_t st);
-// snn_rec16.hip: the recurrent half on half tiles (16 curves per workgroup), LSTM, H = 32 / 64
+// snn_rec16.hip: the recurrent half on half tiles (16 curves per workgroup), LSTM, H = 32 / 64 / 128
 bool snn_rec16_supported(const SnnLayout& y);
 int snn_launch_fwd_rec16(const SnnLayout& y, const FwdParams& p, int l, float* head_part, const float* gx, hipStream_t st);
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
@@ -389,7 +397,10 @@ static int pack_x_launch(const snn_cfg* cfg, const float* x, int64_t stride_t, c
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
-    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, n_tiles < 256 ? 8 : 1), dim3(256),
+    // small batches: a tile's steps are dealt over up to 64 workgroups (those beyond the tile's length leave at once;
+    // with 8, the 300 steps x 78 features of 128 ELAsTiCC-like curves took 354 us on 32 workgroups)
+    const int ny = n_tiles < 256 ? std::max(1, std::min(64, 512 / n_tiles)) : 1;
+    hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, ny), dim3(256),
                        sizeof(float) * PACK_TS * y.Dp * (SNN_TILE + 1), (hipStream_t)stream, y.D, y.Dp, x, stride_t,
                        step_off, stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp, xp_floats);
     HIP_CHECK(hipGetLastError());
@@ -773,7 +784,11 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     // 65 536: 1.55 / 1.40 / 1.30; 131 072: 3.06 / 2.72 / 2.63): independent workgroups leave the balancing to the
     // dispatcher and run the two directions side by side.  The persistent kernel remains for unidirectional models,
     // the GRU / tanh-RNN cells and batches whose head partials do not fit the workspace.
-    const int n_part = e->big ? 4 : y.NW;      // per-wave head partials per phase
+    // while even the half tiles get a compute unit each: 16 curves per workgroup (snn_rec16.hip), half the chain
+    // per step.  SNN_REC16=0|1 forces it off / on (A/B, tests); the backward follows the same rule.
+    const char* f16 = getenv("SNN_REC16");
+    const bool rec16 = train && snn_rec16_supported(y) && (f16 ? f16[0] == '1' : (int64_t)n_tiles * y.dirs * 2 <= g.cus);
+    const int n_part = (e->big && !rec16) ? 4 : y.NW;      // per-wave head partials per phase
     const int64_t part_bytes = (int64_t)sizeof(float) * n_tiles * y.L * y.dirs * n_part * y.C * 32;
     const bool no_layerwise = getenv("SNN_NO_LAYERWISE") != nullptr;   // A/B measurements and tests (read per call)
     // Small batches: input products of a whole layer in one launch over the chip (fwd_gx_kernel), then the recurrent
@@ -791,19 +806,16 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
             const size_t lds = e->big ? sizeof(float) * ((size_t)3 * y.H * 32 + (size_t)5 * y.C * 32) + 16
                                       : sizeof(float) * ((size_t)2 * SNN_TAPE_Q * y.H * 32 + (size_t)2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32) + 16;
             HIP_CHECK(hipFuncSetAttribute((const void*)e->fn_rec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            // while even the half tiles get a compute unit each: 16 curves per workgroup (snn_rec16.hip), half the chain
-            // per step.  SNN_REC16=0|1 forces it off / on (A/B, tests); the backward follows the same rule.
-            const char* f16 = getenv("SNN_REC16");
-            const bool rec16 = snn_rec16_supported(y) && (f16 ? f16[0] == '1' : (int64_t)n_tiles * y.dirs * 2 <= g.cus);
             snprintf(g_last_kernel, sizeof(g_last_kernel), "fwd_gx_kernel + %s<%d,%d,%d,cell%d> x %d layers grid=%d block=%d lds=%zu",
                      rec16 ? "lstm_fwd_rec16_kernel" : e->big ? "lstm_fwd_big_rec_kernel" : "lstm_fwd_rec_kernel", y.H, y.KKI[0],
-                     y.dirs, y.cell, y.L, n_tiles * y.dirs * (rec16 ? 2 : 1), g.threads, lds);
+                     y.dirs, y.cell, y.L, n_tiles * y.dirs * (rec16 ? 2 : 1), rec16 ? y.H * 8 : g.threads,
+                     rec16 ? sizeof(float) * ((size_t)2 * SNN_TAPE_Q * y.H * 16 + (size_t)2 * y.H * 16) : lds);
             for (int l = 0; l < y.L; ++l) {
                 if ((rc = snn_launch_gx(y, p, l, gx, g.cus, st))) return rc;
                 if (rec16) { if ((rc = snn_launch_fwd_rec16(y, p, l, head_part, gx, st))) return rc; }
                 else hipLaunchKernelGGL(e->fn_rec, dim3(n_tiles * y.dirs), dim3(g.threads), lds, st, p, l, head_part, (const float*)gx);
             }
-            hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, n_part, y.dirs, y.k_head_b, head_part);
+            hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(256), sizeof(float) * y.C * 32, st, p, n_part, y.dirs, y.k_head_b, head_part);
             HIP_CHECK(hipGetLastError());
             return SNN_OK;
         }
@@ -815,10 +827,11 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
                  y.H, y.KKI[0], y.dirs, y.L, n_tiles * y.dirs, g.threads, g.lds);
         for (int l = 0; l < y.L; ++l)
             hipLaunchKernelGGL(e->fn_train_layer, dim3(n_tiles * y.dirs), dim3(g.threads), g.lds, st, p, l, head_part);
-        hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(64), 0, st, p, y.NW, y.dirs, y.k_head_b, head_part);
+        hipLaunchKernelGGL(head_combine_kernel, dim3(n_tiles), dim3(256), sizeof(float) * y.C * 32, st, p, y.NW, y.dirs, y.k_head_b, head_part);
         HIP_CHECK(hipGetLastError());
         return SNN_OK;
     }
+    // (n_part / rec16 above concern the split path only: the layer-wise kernel exists for H = 32 / 64, where n_part is NW)
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
     const int64_t n_items = (int64_t)(pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);

@@ -32,7 +32,7 @@ struct GxParams {
 // FIRST: the input is the packed x image; otherwise the h rows of layer l - 1 on the tape.
 // MASKED: variational input / between-layer masks are applied to the operand (as the staging of run_phase does).
 template <int KKI, bool FIRST, bool MASKED>
-__global__ void __launch_bounds__(256, KKI > 64 ? 1 : 2) fwd_gx_kernel(const FwdParams p, const GxParams g)
+__global__ void __launch_bounds__(256, KKI >= 64 ? 1 : 2) fwd_gx_kernel(const FwdParams p, const GxParams g)
 {
     constexpr int KB = KKI < 32 ? KKI : 32;   // operand loads issued per batch, ahead of their MFMAs
     const int H = g.H, dirs = g.dirs, l = g.l, NWT = H / 8;
@@ -84,7 +84,40 @@ __global__ void __launch_bounds__(256, KKI > 64 ? 1 : 2) fwd_gx_kernel(const Fwd
     const float* in0 = FIRST ? p.xp + p.tile_off[tile] : p.tape + (int64_t)tile * p.tape_tile + (int64_t)(l - 1) * dirs * p.max_T * ts + 5 * H * 32;
     float* out0 = g.gx + ((((int64_t)tile * dirs + d) * p.max_T) * NWT + tau) * 1024 + lane;
 
-    for (int t = t0; t < t1; ++t) {
+    // The operands of batch b + 1 (KB k-steps; the next step's first batch after a step's last) are requested before the
+    // MFMAs of batch b are issued: a wave then waits for memory once per chunk instead of once per batch (with one
+    // batch in flight at a time the 256-wide layer-1 input of H = 128 ran at a sixth of the MFMA rate: 4 dependent
+    // round trips per step beside 4 x 32 MFMAs).  NB batches per step; buffers alternate, statically: for an odd NB the
+    // step loop is unrolled by two.
+    constexpr int NB = (KKI + KB - 1) / KB;
+    auto load_batch = [&](int t, int b, float (&bq)[KB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int kk = b * KB + k;
+            if (kk < KKI) {
+                const float* src;
+                if (FIRST) src = in0 + (int64_t)t * (2 * KKI * 32) + kk * 64 + lane;
+                else {
+                    const int dd = 2 * kk >= H ? 1 : 0;     // (dirs <= 2) rows 2 kk and 2 kk + 1 lie in the same direction block: H is even
+                    src = in0 + ((int64_t)dd * p.max_T + t) * ts + (2 * kk - dd * H) * 32 + lane;
+                }
+                bq[k] = *src;
+            }
+        }
+    };
+    auto mfma_batch = [&](int b, const float (&bq)[KB], f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int kk = b * KB + k;
+            if (kk < KKI) {
+                float bv = bq[k];
+                if (MASKED) bv = __fmul_rn(mlds[kk * 64 + lane], bv);   // feature 2 kk + hf of curve cl
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[kk], bv, acc, 0, 0, 0);
+            }
+        }
+    };
+    // one step: its NB batches from buffers (first, other, first, ...); the last batch prefetches step t + 1 into `nxt`
+    auto step = [&](int t, float (&first)[KB], float (&other)[KB], float (&nxt)[KB]) __attribute__((always_inline)) {
         if (MASKED && mid_step) {       // block-uniform
             __syncthreads();
             fill_masks(t);
@@ -92,36 +125,29 @@ __global__ void __launch_bounds__(256, KKI > 64 ? 1 : 2) fwd_gx_kernel(const Fwd
         }
         f32x16 acc = binit;
 #pragma unroll
-        for (int k0 = 0; k0 < KKI; k0 += KB) {
-            float bq[KB];
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                const int kk = k0 + k;
-                if (kk < KKI) {
-                    const float* src;
-                    if (FIRST) src = in0 + (int64_t)t * (2 * KKI * 32) + kk * 64 + lane;
-                    else {
-                        const int dd = 2 * kk >= H ? 1 : 0;     // (dirs <= 2) rows 2 kk and 2 kk + 1 lie in the same direction block: H is even
-                        src = in0 + ((int64_t)dd * p.max_T + t) * ts + (2 * kk - dd * H) * 32 + lane;
-                    }
-                    bq[k] = *src;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                const int kk = k0 + k;
-                if (kk < KKI) {
-                    float bv = bq[k];
-                    if (MASKED) bv = __fmul_rn(mlds[kk * 64 + lane], bv);   // feature 2 kk + hf of curve cl
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[kk], bv, acc, 0, 0, 0);
-                }
-            }
+        for (int b = 0; b < NB; ++b) {
+            float (&cur)[KB] = (b & 1) ? other : first;
+            if (b + 1 < NB) load_batch(t, b + 1, (b & 1) ? first : other);
+            else if (t + 1 < t1) load_batch(t + 1, 0, nxt);
+            mfma_batch(b, cur, acc);
         }
         if (active) {
             float* o = out0 + (int64_t)t * NWT * 1024;
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i * 64] = acc[i];
         }
+    };
+    float bqa[KB], bqb[KB];
+    load_batch(t0, 0, bqa);
+    if (NB % 2 == 0) {
+        for (int t = t0; t < t1; ++t) step(t, bqa, bqb, bqa);
+    } else {
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+            step(t, bqa, bqb, bqb);
+            step(t + 1, bqb, bqa, bqa);
+        }
+        if (t < t1) step(t, bqa, bqb, bqb);
     }
 }
 

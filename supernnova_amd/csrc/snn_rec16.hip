@@ -7,7 +7,9 @@
 // workgroup on v_mfma_f32_16x16x4_f32 (16 x 32 cycles per wave and step) and 2 hidden units per lane -- half the
 // chain, twice the workgroups.  Memory layouts stay those of the 32-curve kernels (tape [q][H][32], Gx in the
 // 32x32 C/D image, dG [4H][32]): a workgroup reads and writes its 16 columns, so fwd_gx_kernel, bwd_dx_kernel,
-// bwd_dw_kernel and the head kernels are unchanged.  LSTM cell, H = 32 / 64.  v_mfma_f32_16x16x4_f32 adds its four
+// bwd_dw_kernel and the head kernels are unchanged.  LSTM cell, H = 32 / 64 / 128 (H = 128: 16 waves forward, each with
+// its 2 x 32 k-steps of W_hh in registers; 8 waves backward with 128 k-steps of W_hh^T each -- the chain per step is
+// 64 / 128 MFMAs of 32 cycles where the 32-curve kernels of snn_forward_big.hip / bwd_rec_kernel<128> run 256 of 64).  v_mfma_f32_16x16x4_f32 adds its four
 // products in another order than two v_mfma_f32_32x32x2_f32, so results differ from the 32-curve kernels by fp32
 // rounding (same parity bar against the reference fixtures; tests/test_gpu_train.py).
 //
@@ -169,14 +171,15 @@ __global__ void __launch_bounds__(H * 8) lstm_fwd_rec16_kernel(const FwdParams p
 
 typedef void (*rec16_fwd_t)(const FwdParams, const Rec16Params, int, float*, const float*);
 
-bool snn_rec16_supported(const SnnLayout& y) { return y.cell == 0 && y.prec == 0 && (y.H == 32 || y.H == 64) && y.dirs <= 2; }
+bool snn_rec16_supported(const SnnLayout& y) { return y.cell == 0 && y.prec == 0 && (y.H == 32 || y.H == 64 || y.H == 128) && y.dirs <= 2; }
 
 // recurrent half of layer l of a training forward on half tiles; gx from fwd_gx_kernel; head_part as lstm_fwd_rec_kernel's
 int snn_launch_fwd_rec16(const SnnLayout& y, const FwdParams& p, int l, float* head_part, const float* gx, hipStream_t st)
 {
     const bool masked = p.mk.mode != SNN_MASK_NONE;
     rec16_fwd_t fn = y.H == 32 ? (masked ? lstm_fwd_rec16_kernel<32, true> : lstm_fwd_rec16_kernel<32, false>)
-                               : (masked ? lstm_fwd_rec16_kernel<64, true> : lstm_fwd_rec16_kernel<64, false>);
+                   : y.H == 64 ? (masked ? lstm_fwd_rec16_kernel<64, true> : lstm_fwd_rec16_kernel<64, false>)
+                               : (masked ? lstm_fwd_rec16_kernel<128, true> : lstm_fwd_rec16_kernel<128, false>);
     Rec16Params r;
     r.dirs = y.dirs; r.KK = y.KK[l]; r.KKI = y.KKI[l]; r.k_head_w = y.k_head_w;
     for (int d = 0; d < y.dirs; ++d) r.k_A[d] = y.k_A[l * y.dirs + d];
@@ -193,12 +196,15 @@ int snn_launch_fwd_rec16(const SnnLayout& y, const FwdParams& p, int l, float* h
 // backward: gate gradients from the tape + dh_{t-1} = W_hh^T dG_t, half a tile per workgroup (bwd_rec_kernel<H, 0>)
 // ============================================================================================================
 template <int H>
-__global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int l)
+__global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const Bwd2Params p, int l)
 {
+    constexpr int NTH = H == 128 ? 512 : 256, NWV = NTH / 64;
     constexpr int MB = H / 16;          // 16-unit blocks of dh
-    constexpr int KSPLIT = 4 / MB;      // waves sharing one block (split over the gate rows)
+    constexpr int KSPLIT = NWV / MB;    // waves sharing one block (split over the gate rows)
     constexpr int KW = H / KSPLIT;      // k-steps (of 4 gate rows) per wave
-    constexpr int UPT = H / 32;         // (hidden unit, 2 curves) items per thread in the element-wise stage
+    constexpr int UPT = H * 8 / NTH;    // (hidden unit, 2 curves) items per thread in the element-wise stage
+    constexpr int JS = NTH / 8;         // unit stride of a thread's items
+    static_assert(KSPLIT >= 1 && MB * KSPLIT == NWV, "one 16-unit block (or a K share of one) per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dGl = smem;                  // [4H][16] gate gradients of the running step (B operand image)
     float* red = dGl + 4 * H * 16;      // [KSPLIT][H][16]
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int T = p.tile_T[tile];
     const bool last_layer = l == y.L - 1;
-    const int c2 = (tid & 7) * 2, jg = tid >> 3;      // element-wise stage: 2 consecutive curves of units jg, jg + 32, ...
+    const int c2 = (tid & 7) * 2, jg = tid >> 3;      // element-wise stage: 2 consecutive curves of units jg, jg + JS, ...
     const int cg2 = 16 * half + c2;
     int len[2];
     float inv_len[2];
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int 
     f32x2 dc[UPT], dhr[UPT], dfm[UPT];
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-        const int j = jg + 32 * i;
+        const int j = jg + JS * i;
         dc[i] = zero2;
         dhr[i] = y.pool == SNN_POOL_STANDARD ? *reinterpret_cast<const f32x2*>(dfeat + (j * (y.L * dirs) + ld) * 32 + cg2) : zero2;
         dfm[i] = zero2;
@@ -258,7 +264,7 @@ __global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int 
         const float* tq = tape_ld + (int64_t)t * ts + cg2;
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 32 * i;
+            const int j = jg + JS * i;
             n_ig[i] = *reinterpret_cast<const f32x2*>(tq + (0 * H + j) * 32);
             n_fg[i] = *reinterpret_cast<const f32x2*>(tq + (1 * H + j) * 32);
             n_gg[i] = *reinterpret_cast<const f32x2*>(tq + (2 * H + j) * 32);
@@ -281,7 +287,7 @@ __global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int 
         if (step > 0) fetch(tp);   // n_cn is then c of the previous step: the cell state this step started from
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 32 * i;
+            const int j = jg + JS * i;
             f32x2 dai = zero2, daf = zero2, dag = zero2, dao = zero2;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(256) bwd_rec16_kernel(const Bwd2Params p, int 
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            const int j = jg + 32 * i;
+            const int j = jg + JS * i;
             f32x2 s = zero2;
 #pragma unroll
             for (int k = 0; k < KSPLIT; ++k) {
@@ -340,7 +346,9 @@ int snn_launch_bwd_rec16(const Bwd2Params& p, int l, hipStream_t st)
 {
     const SnnLayout& y = p.lay;
     const size_t lds = sizeof(float) * ((size_t)4 * y.H * 16 + (size_t)(y.H == 32 ? 2 : 1) * y.H * 16);
-    if (y.H == 32) hipLaunchKernelGGL(bwd_rec16_kernel<32>, dim3(p.n_tiles * y.dirs * 2), dim3(256), lds, st, p, l);
-    else hipLaunchKernelGGL(bwd_rec16_kernel<64>, dim3(p.n_tiles * y.dirs * 2), dim3(256), lds, st, p, l);
+    const dim3 grid(p.n_tiles * y.dirs * 2);
+    if (y.H == 32) hipLaunchKernelGGL(bwd_rec16_kernel<32>, grid, dim3(256), lds, st, p, l);
+    else if (y.H == 64) hipLaunchKernelGGL(bwd_rec16_kernel<64>, grid, dim3(256), lds, st, p, l);
+    else hipLaunchKernelGGL(bwd_rec16_kernel<128>, grid, dim3(512), lds, st, p, l);
     return SNN_OK;
 }

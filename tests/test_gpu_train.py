@@ -702,6 +702,8 @@ def test_one_call_train_step_equals_the_call_by_call_sequence(model):
     (42, 64, 2, True, "mean", 5, "locked", 65, 11),
     (78, 64, 1, True, "standard", 14, None, 17, 30),
     (24, 32, 2, True, "mean", 2, None, 1, 1),
+    (78, 128, 2, True, "mean", 14, None, 45, 37),
+    (26, 128, 2, False, "standard", 3, "locked", 33, 9),
 ])
 def test_half_tile_recurrent_kernels_match_the_32_curve_kernels(D, H, L, bidir, pool, C, masked, n, T):
     """16 curves per workgroup on v_mfma_f32_16x16x4_f32 (snn_rec16.hip), forward and backward: the same arithmetic in
