@@ -828,7 +828,10 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     float* dyA = p.dfeat + g.dfeat_floats + g.n_dG * g.dG_floats;
     float* dyB = dyA + g.dy_floats;
     const bool small = g.n_dG > 1 || (y.L == 1 && small_batch(y, p.n_tiles));   // (see small_batch)
-    const bool rec16 = small && snn_rec16_supported(y);
+    // half tiles: always for small batches; at H = 128 for every size (two waves per SIMD with 128 k-steps of W_hh^T
+    // each cover each other's tape loads where bwd_rec_kernel<128> has one wave per SIMD: backward 73.4 -> 68.2 ms at
+    // 8192 curves x 300 steps; at H = 64 the 32-curve kernel is the faster one at size: 10.5 against 11.7 ms)
+    const bool rec16 = snn_rec16_supported(y) && (small || H == 128);
     const bool overlap = g.n_dG == y.L && y.L > 1;
     SideStream* side = nullptr;
     if (overlap && side_stream(&side) != SNN_OK) return SNN_ERR_HIP;
