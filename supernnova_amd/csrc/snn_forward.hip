@@ -399,7 +399,7 @@ static int pack_x_launch(const snn_cfg* cfg, const float* x, int64_t stride_t, c
     }
     // small batches: a tile's steps are dealt over up to 64 workgroups (those beyond the tile's length leave at once;
     // with 8, the 300 steps x 78 features of 128 ELAsTiCC-like curves took 354 us on 32 workgroups)
-    const int ny = std::max(1, std::min(64, 2048 / n_tiles));      // ~8 workgroups per compute unit
+    const int ny = std::max(1, std::min(64, 8192 / n_tiles));      // (tiles are sorted by length: small workgroups balance)
     hipLaunchKernelGGL(pack_x_kernel, dim3(n_tiles, ny), dim3(256),
                        sizeof(float) * PACK_TS * y.Dp * (SNN_TILE + 1), (hipStream_t)stream, y.D, y.Dp, x, stride_t,
                        step_off, stride_n, curve_off, order, len_sorted, tile_T, tile_off, xp, xp_floats);
