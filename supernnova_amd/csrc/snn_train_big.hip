@@ -842,7 +842,8 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
     // half tiles: always for small batches; at H = 128 for every size (two waves per SIMD with 128 k-steps of W_hh^T
     // each cover each other's tape loads where bwd_rec_kernel<128> has one wave per SIMD: backward 73.4 -> 68.2 ms at
     // 8192 curves x 300 steps; at H = 64 the 32-curve kernel is the faster one at size: 10.5 against 11.7 ms)
-    const bool rec16 = snn_rec16_supported(y) && (small || H == 128);
+    const char* f16 = getenv("SNN_REC16");      // "0": the 32-curve kernels everywhere (A/B, tests)
+    const bool rec16 = snn_rec16_supported(y) && (small || (H == 128 && !(f16 && f16[0] == '0')));
     const bool overlap = g.n_dG == y.L && y.L > 1;
     SideStream* side = nullptr;
     if (overlap && side_stream(&side) != SNN_OK) return SNN_ERR_HIP;

@@ -748,6 +748,28 @@ def test_half_tile_recurrent_kernels_match_the_32_curve_kernels(D, H, L, bidir, 
     _grad_check(b[2].cpu().numpy(), a[2].cpu().numpy(), "half-tile vs 32-curve gradient")
 
 
+def test_h128_backward_takes_half_tiles_at_every_size():
+    """At H = 128 the backward runs its recurrent kernel on half tiles whatever the batch size (snn_train_big.hip); for a
+    batch beyond the small-batch rule (66 tiles x 2 directions x 2 halves > compute units: one dG buffer, no side
+    stream) its gradients equal those of the 32-curve kernel (SNN_REC16=0) on the same tape to GRAD_RTOL."""
+    import os
+    from supernnova_amd import engine as E
+    cfg = E.Config(24, 128, 2, True, 3, "mean")
+    res = {}
+    for r16 in ("0", None):
+        if r16 is not None:
+            os.environ["SNN_REC16"] = r16
+        try:
+            plan, out, names = _forward_train_variants(cfg, 2100, 3, lambda plan: None, variants=("0",))
+        finally:
+            os.environ.pop("SNN_REC16", None)
+        assert "rec16" not in names[0] and plan.n_tiles == 66
+        res[r16] = out[0]
+    assert torch.equal(res["0"][0], res[None][0])        # same forward kernel: same logits and tape
+    _grad_check(res[None][2].cpu().numpy(), res["0"][2].cpu().numpy(), "H=128 half-tile backward at 2100 curves")
+    assert not torch.equal(res[None][2], res["0"][2])    # (another MFMA shape: the two paths are different kernels)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tag", ["t13", "t300"])
 def test_train_step_at_the_elasticc_shape_vs_reference(tag, fused):
