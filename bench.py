@@ -81,9 +81,10 @@ def bayes_init(cfg, seed, device):
 def flops_per_pass(cfg, lengths_sum, n_curves, S):
     """per curve per sample l*16H(D+4H) + 4HC (L=2, bidirectional); a GRU has 3 gates' rows and a tanh RNN 1
     where the LSTM has 4 (algorithmic FLOPs: rows the kernels pad to a full MFMA tile are not counted)."""
-    H, D, C = cfg.hidden_size, cfg.input_size, cfg.nb_classes
+    H, D, C, nd = cfg.hidden_size, cfg.input_size, cfg.nb_classes, cfg.dirs
     ng = {"lstm": 4, "gru": 3, "rnn": 1}[cfg.cell]
-    return S * (lengths_sum * 4 * ng * H * (D + 4 * H) + n_curves * 4 * H * C)
+    # per direction and step: 2 ng H (D + H) in layer 0, 2 ng H (dirs H + H) in layer 1; head: 2 (dirs H) C
+    return S * (lengths_sum * nd * 2 * ng * H * (D + (2 + nd) * H) + n_curves * 2 * nd * H * C)
 
 
 def cpu_baseline(cfg, x_host, lengths_host, mu, rho, S, n_curves, model="bayesian"):
@@ -223,7 +224,7 @@ def run(args, rank, world, dev, backend, dist):
         if args.samples == 50:
             args.samples = 1          # (validate_rnn.py:528-529: a VanillaRNN is classified with one forward)
     else:
-        cfg = E.Config(24, 64 if args.workload == "h64" else 32, 2, True, 2, "mean")
+        cfg = E.Config(24, 64 if args.workload == "h64" else 32, 2, args.workload != "uni", 2, "mean")
     cfg = cfg.with_precision(args.precision)
     S, N = args.samples, args.curves
     mu, rho = bayes_init(cfg, 0, dev)
@@ -388,7 +389,7 @@ def run(args, rank, world, dev, backend, dist):
                                    (f"VanillaRNN, layer_type={args.workload} (training/vanilla_rnn.py:26-32), 32x2 bidirectional, "
                                     f"mean pooling, D=24 (4 filters), C=2, {S} forward per curve, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU") if plain else
-                                   (f"BayesianRNN (BBB) LSTM {cfg.hidden_size}x2 bidirectional, mean pooling, D=24 (4 filters), "
+                                   (f"BayesianRNN (BBB) LSTM {cfg.hidden_size}x2 {'bidirectional' if cfg.bidirectional else 'unidirectional'}, mean pooling, D=24 (4 filters), "
                                     f"C=2, S={S} MC samples, lengths U{{3..{args.max_len}}}, "
                                     f"{N} light curves per GPU (configs[2]: 10M over 8 GPUs)"),
                        "curves_per_gpu": N, "samples": S, "max_len": args.max_len, "parallelism": f"shard{world}"},
@@ -468,11 +469,11 @@ def main():
     ap.add_argument("--curves", type=int, default=1_250_000, help="light curves per GPU (10M / 8)")
     ap.add_argument("--samples", type=int, default=50)
     ap.add_argument("--max-len", type=int, default=40)
-    ap.add_argument("--workload", choices=["des", "elasticc", "variational", "h64", "gru", "rnn"], default="des",
+    ap.add_argument("--workload", choices=["des", "elasticc", "variational", "h64", "uni", "gru", "rnn"], default="des",
                     help="des: BASELINE metric config (H=32, 4 filters, lengths U{3..40}); elasticc: configs[4] "
                          "(H=128, 6 filters + redshift, 14 classes, 300-step sequences); variational: configs[1] "
                          "(VariationalRNN MC dropout p=0.05, Philox masks in-kernel, same shapes as des); h64: des with "
-                         "hidden_dim 64; gru / rnn: VanillaRNN with settings.layer_type gru / rnn, one forward per curve "
+                         "hidden_dim 64; uni: des with bidirectional=False; gru / rnn: VanillaRNN with settings.layer_type gru / rnn, one forward per curve "
                          "-- all but des are secondary measurements")
     ap.add_argument("--cpu-curves", type=int, default=3840, help="curves of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-selfcheck", action="store_true",
@@ -484,7 +485,7 @@ def main():
                     help="also time the CPU port with the BASELINE.md 3 protocol (12 800 curves, median of 3, and 1 thread): "
                          "several minutes of CPU work")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary workloads (variational, elasticc, h64, gru, rnn) the default run appends as `secondary`")
+                    help="skip the secondary workloads (variational, elasticc, h64, uni, gru, rnn) the default run appends as `secondary`")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the training measurements (BASELINE configs[3]) the default run appends as secondary.train "
                          "and a --gpus N run as train_dp")
@@ -525,7 +526,7 @@ def main():
         # ELAsTiCC-like H = 128 / 300-step model), two timed steps each, so that the line the driver records carries them
         import copy
         out["secondary"] = {}
-        for wl in ("variational", "elasticc", "h64", "gru", "rnn"):
+        for wl in ("variational", "elasticc", "h64", "uni", "gru", "rnn"):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_curves = wl, 2, 1, 0
             if wl == "h64":

@@ -9,7 +9,8 @@ fail() { echo "FAILED: $1"; tail -5 $2; exit 1; }
 if [ "$1" != "skipbench" ]; then
   timeout -k 10 560 python3 $R/bench.py > $O/bench_default.json.log 2>&1 || fail "default bench" $O/bench_default.json.log
 fi
-for wl in des variational elasticc h64 gru rnn; do
+WLS=${WLS:-"des variational elasticc h64 uni gru rnn"}
+for wl in $WLS; do
   EXTRA=""; [ $wl = h64 ] && EXTRA="--curves 312500"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 $R/bench.py --workload $wl $EXTRA $COMMON --steps 3 --warmup 1 > $O/kt_$wl.log 2>&1 || fail "kernel trace $wl" $O/kt_$wl.log
   cp $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) $O/bench_${wl}_kernel_stats.csv

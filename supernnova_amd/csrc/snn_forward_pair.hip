@@ -419,13 +419,17 @@ __global__ void __launch_bounds__(H * 8, MASKED ? SNN_PAIR_MASKED_WAVES : SNN_PA
 typedef void (*fwd_kernel_t)(const FwdParams);
 fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs, bool masked)
 {
-    if (H == 32 && dirs == 2) {   // every layer-0 width bucket of snn_layout.h
-#define SNN_PAIR_CASE(K) if (KKI0 == K) return masked ? lstm_fwd_pair_kernel<32, K, 2, true> : lstm_fwd_pair_kernel<32, K, 2, false>
-        SNN_PAIR_CASE(12);
-        SNN_PAIR_CASE(13);
-        SNN_PAIR_CASE(24);
-        SNN_PAIR_CASE(38);
-        SNN_PAIR_CASE(39);
+    if (H == 32 && (dirs == 2 || dirs == 1)) {   // every layer-0 width bucket of snn_layout.h, both direction counts
+#define SNN_PAIR_CASE(K)                                                                                                   \
+    if (KKI0 == K) {                                                                                                       \
+        if (dirs == 2) return masked ? lstm_fwd_pair_kernel<32, K, 2, true> : lstm_fwd_pair_kernel<32, K, 2, false>;        \
+        return masked ? lstm_fwd_pair_kernel<32, K, 1, true> : lstm_fwd_pair_kernel<32, K, 1, false>;                      \
+    }
+        SNN_PAIR_CASE(12)
+        SNN_PAIR_CASE(13)
+        SNN_PAIR_CASE(24)
+        SNN_PAIR_CASE(38)
+        SNN_PAIR_CASE(39)
 #undef SNN_PAIR_CASE
     }
     return nullptr;
