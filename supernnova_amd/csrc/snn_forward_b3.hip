@@ -27,14 +27,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BLK_U4 = 3 * 64;   // uint4 (16-byte) words of one K=16 block: 3 pieces x 64 lanes
 
-// mask bit of the lane ? a : b, as one opaque v_cndmask (see snn_forward_pair.hip)
-__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
-    return r;
-}
-
 // Tiles of one work item: the weights of a (layer, direction) are loaded once and G tiles run through them.
 constexpr int B3_G = 4;
 struct B3Group {

@@ -31,12 +31,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BLK_U4 = 3 * 64;   // uint4 (16-byte) words of one K=16 block: 3 pieces x 64 lanes
 constexpr int B3_G = 4;          // tiles of one work item (two pairs), as in snn_forward_b3.hip
 
-__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
-    return r;
-}
 // two floats -> two bf16 (round to nearest even) in one register, low half = a
 __device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b)
 {

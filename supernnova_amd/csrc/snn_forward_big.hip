@@ -181,13 +181,14 @@ pass2:
             for (int kk = 0; kk < KKH; ++kk) wh[r][kk] = __fmul_rn(m, wh[r][kk]);
         }
     }
-    // locked between-layer mask of this lane's units, parked in LDS: mlds[unit][curve]
+    // locked between-layer mask of this lane's units, parked in LDS: mlds[unit][curve] (1.0 without masks: the y
+    // stores below multiply unconditionally, x * 1.0f == x bit for bit)
     const bool use_mid = masked && !last_layer && !TRAIN;
-    if (use_mid) {
+    if (!last_layer && !TRAIN) {
         for (int idx = c.tid; idx < H * 32; idx += NT) {
             const int j = idx >> 5, cc = idx & 31;
             const int o = p.order[c.tile * SNN_TILE + cc];
-            mlds[idx] = o >= 0 ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, o, d * H + j) : 1.0f;
+            mlds[idx] = (use_mid && o >= 0) ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, o, d * H + j) : 1.0f;
         }
     }
     float cst[RT][4], hst[RT][4], hsum[RT][4];
@@ -209,11 +210,14 @@ pass2:
         }
     }
     lds_barrier();
+    // The step body is ONE straight-line block: the "still inside the curve" selects are v_cndmask on a ballot (a C++
+    // select let the compiler sink each cell update under its own exec-mask branch: ~40 branches per step), the Gx of
+    // the step after the last is a (clamped, unused) reload of the last one, and the only branch left -- last layer or
+    // not -- is uniform and sits behind the activations.
     for (int step = 0; step < T; ++step) {
         const int t = d == 0 ? step : T - 1 - step;
-        const int tn = d == 0 ? t + 1 : t - 1;
+        const int tn = d == 0 ? (t + 1 < T ? t + 1 : t) : (t > 0 ? t - 1 : 0);
         const int cur = step & 1;
-        const bool more = step + 1 < T;
         const float* hc = hb + cur * (H * 32) + c.lane;
 #pragma unroll
         for (int kk = 0; kk < KKH; ++kk) {
@@ -221,12 +225,12 @@ pass2:
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
         }
-        const bool valid = t < c.len;
+        const unsigned long long vmask = __builtin_amdgcn_ballot_w64(t < c.len);
+        float outv[RT][4];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
             float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
-            float outv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float ig = snn_sigmoid(acc[r][u]);
@@ -235,9 +239,9 @@ pass2:
                 const float og = snn_sigmoid(acc[r][12 + u]);
                 const float cn = fmaf(fg, cst[r][u], __fmul_rn(ig, gg));
                 const float hv = og * snn_tanh(cn);
-                cst[r][u] = valid ? cn : cst[r][u];
-                hst[r][u] = valid ? hv : hst[r][u];
-                outv[u] = valid ? hv : 0.0f;
+                cst[r][u] = lane_select(vmask, cn, cst[r][u]);
+                hst[r][u] = lane_select(vmask, hv, hst[r][u]);
+                outv[r][u] = lane_select(vmask, hv, 0.0f);
                 hn[u * 32] = hst[r][u];
                 if (TRAIN) {
                     float* tp = tape_ld + (int64_t)t * tape_step_floats(H) + (j0 + u) * 32 + c.cl;
@@ -246,28 +250,30 @@ pass2:
                     tp[2 * H * 32] = gg;
                     tp[3 * H * 32] = og;
                     tp[4 * H * 32] = cn;
-                    tp[5 * H * 32] = outv[u];
+                    tp[5 * H * 32] = outv[r][u];
                 }
             }
             // the next step's Gx for this tile goes straight into the now-free accumulator
-#ifdef SNN_ABL_BIG_NOGX   // timing ablation only (results are wrong): no Gx reload
-            if (more && p.n_curves < 0)
-#else
-            if (more)
-#endif
+#ifndef SNN_ABL_BIG_NOGX   // (timing ablation only, results are wrong: no Gx reload)
             {
                 const float* g = gx + ((int64_t)tn * NWT + (c.w * RT + r)) * 1024 + c.lane;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
             }
-            if (last_layer) {
+#endif
+        }
+        if (last_layer) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hsum[r][u] += outv[u];
-            } else if (!TRAIN) {
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hsum[r][u] += outv[r][u];
+        } else if (!TRAIN) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
                 float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    yo[u * 32] = use_mid ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[u]) : outv[u];
+                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[r][u]);
             }
         }
         lds_barrier();

@@ -33,12 +33,6 @@ constexpr int BLK_U4 = 2 * 64;   // uint4 (16-byte) words of one K=16 block: 2 p
 constexpr int B3_G = SNN_H2_G;   // tiles of one work item (snn_kernels.h)
 static_assert(B3_G % 2 == 0, "a work item is a whole number of tile pairs (the y slab has B3_G tile slots)");
 
-__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
-    return r;
-}
 // two floats -> two fp16 (round to nearest even) in one register, low half = a
 __device__ __forceinline__ unsigned int cvt_pk_f16(float a, float b)
 {

@@ -40,16 +40,6 @@ struct PairCtx {
     float* ybase;           // this workgroup's y scratch: [nbuf][2 tiles][dirs][max_T][H*32]
 };
 
-// mask bit of the lane ? a : b, as one opaque v_cndmask.  Written as (pure) inline asm because a C++ select lets
-// the compiler sink the whole cell update under an `if (valid)` branch, which splits a pipeline phase into
-// basic blocks and forbids the MFMA/VALU interleave the phase exists for.
-__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
-{
-    float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
-    return r;
-}
-
 // UNIFORM: every curve of both tiles runs all T steps of the pair (the usual case: curves are sorted by length, and a
 // length class of a large batch spans many tiles) -- the per-lane "still inside the curve" selects of the cell update
 // drop out (3 of ~32 vector instructions per hidden unit and step, on the pipe the fp32 MFMAs share).  Same values.

@@ -146,6 +146,16 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
 
 // LDS-only barrier: global stores of the step stay in flight (they are only
 // read after a later __syncthreads()).
+// mask bit of the lane ? a : b, as one opaque v_cndmask.  Written as (pure) inline asm because a C++ select lets
+// the compiler sink the whole cell update under an `if (valid)` branch, which splits a pipeline phase into
+// basic blocks and forbids the MFMA/VALU interleave the phase exists for.
+__device__ __forceinline__ float lane_select(unsigned long long mask, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
 #ifdef SNN_ABL_NOBAR   // timing ablation only (results are wrong): what the per-step rendezvous costs
