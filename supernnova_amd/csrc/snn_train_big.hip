@@ -342,15 +342,19 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
             const float* A = p.WT + p.wt_ih[ld] + (int64_t)mt * 2 * H * 64 + lane;
             const float* B = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t0) * 4 * H * 32 + lane;
             // operands stream from L2: issue a batch of KB k-steps' loads, then their MFMAs (steps beyond the
-            // tile's last one read the next step's rows of the same buffer and are never stored)
+            // tile's last one read the next step's rows of the same buffer and are never stored; steps beyond the
+            // buffer re-read its last step: unconditional loads, no branch and no wait between them)
             constexpr int KB = TSW == 4 ? 16 : 32;
+            int sc[TSW];
+#pragma unroll
+            for (int s = 0; s < TSW; ++s) sc[s] = t0 + s < p.max_T ? s : p.max_T - 1 - t0;
             for (int k0 = 0; k0 < 2 * H; k0 += KB) {
                 float a[KB], b[TSW][KB];
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
                     a[k] = A[(k0 + k) * 64];
 #pragma unroll
-                    for (int s = 0; s < TSW; ++s) b[s][k] = (t0 + s < p.max_T) ? B[(int64_t)s * 4 * H * 32 + (k0 + k) * 64] : 0.0f;
+                    for (int s = 0; s < TSW; ++s) b[s][k] = B[(int64_t)sc[s] * 4 * H * 32 + (k0 + k) * 64];
                 }
 #pragma unroll
                 for (int k = 0; k < KB; ++k)
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(256) bwd_dx_kernel(const Bwd2Params p, int l, 
 // OCC = workgroups per compute unit: 2 while the accumulators leave room (<= 7 column tiles; H=64 layer 1 14.6 against
 // 15.6 ms per step at 65 536 curves).  Double-buffered LDS images (one barrier per tile-step) measured the same as
 // single ones at either occupancy and are not kept.
-template <int H, int NTN, int OCC>
+template <int H, int NTN, int OCC, bool MASKED>
 __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, int l, int n_chunks)
 {
     constexpr int MG = 4 * H / 128;   // groups of 128 gate rows (one 32-row tile per wave)
@@ -398,7 +402,9 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
     const int ld = l * dirs + d;
     const int I = y.I[l];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, cl = lane & 31, hf = lane >> 5;
-    const bool masked = p.mk.mode != SNN_MASK_NONE;
+    // MASKED = false is launched for models without dropout masks only: the Philox mask code (a few thousand
+    // instructions behind run-time branches in the fetch) is not in that kernel at all
+    const bool masked = MASKED && p.mk.mode != SNN_MASK_NONE;
     const int64_t ts = tape_step_floats(H);
     f32x16 acc[NTN];
 #pragma unroll
@@ -423,51 +429,60 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
         tile = lo;
         t = (int)(v0 - p.tile_off[lo] / xsf);
     }
+    // Per-tile values of the fetch cursor, read when it enters a tile and kept in scalar registers: read per tile-step
+    // (tile_T twice, tile_off once, each a dependent scalar load in front of the step's fetch) they stood between every
+    // two MFMA blocks.
+    int T_f = 0;
+    const float *tape_f = nullptr, *x_f = nullptr, *dG_f = nullptr;
+    auto enter_tile = [&](int tile) __attribute__((always_inline)) {
+        T_f = p.tile_T[tile];
+        tape_f = p.tape + (int64_t)tile * p.tape_tile;
+        x_f = p.xp + p.tile_off[tile];
+        dG_f = p.dG + ((int64_t)tile * dirs + d) * p.max_T * 4 * H * 32 + (int64_t)mg * 128 * 32;
+    };
     // Software pipeline over the chunk's tile-steps: the operands of the next tile-step are fetched into registers
     // while the MFMAs of the current one run from LDS (an un-overlapped fetch was ~60 % of the kernel's time).
     f32x4 gv[4], xv[NTN];   // 128 dG rows and NTN * 32 [h_prev | x_t | 1 | 0] rows, 8 float4 per row, 256 threads
+    // Branch-free: every load is unconditional at a clamped address and rows without a source are chosen by selects
+    // afterwards.  With the rows' cases written as branches the compiler put s_waitcnt vmcnt(0) at the joins (a register
+    // written by a load on one path and by a move on the other), so each load of a fetch waited for the one before it:
+    // clock64 probes read 5 200 cycles per tile-step for the 17 loads of H = 128 / layer 1 beside 13 300 cycles of MFMAs.
     auto fetch = [&](int tile, int t) __attribute__((always_inline)) {
-        const int T = p.tile_T[tile];
-        const float* tape = p.tape + (int64_t)tile * p.tape_tile;
-        const float* src = p.dG + (((int64_t)tile * dirs + d) * p.max_T + t) * 4 * H * 32 + (int64_t)mg * 128 * 32;
+        const float* src = dG_f + (int64_t)t * 4 * H * 32;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
             gv[i] = *reinterpret_cast<const f32x4*>(src + row * 32 + c4);
         }
-        const int tp = d == 0 ? t - 1 : t + 1;
-        const bool first = d == 0 ? t == 0 : t == T - 1;   // first processed step of this direction: h_prev = 0
-        const float* xtile = p.xp + p.tile_off[tile];
+        const bool first = d == 0 ? t == 0 : t == T_f - 1;   // first processed step of this direction: h_prev = 0
+        const int tp = first ? t : (d == 0 ? t - 1 : t + 1);
+        const float* hsrc = tape_f + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32;
+        const float* xsrc0 = x_f + (int64_t)t * y.Dp * 32;                       // layer 0: packed input rows of step t
+        const float* ysrc = tape_f + (int64_t)t * ts + 5 * H * 32;               // layer > 0: outputs of the layer below
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < NTN; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < H) {
-                if (!first) v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32 + row * 32 + c4);
-            } else if (row < H + I) {
-                const int k = row - H;
-                if (l == 0) {
-                    v = *reinterpret_cast<const f32x4*>(xtile + ((int64_t)t * y.Dp + k) * 32 + c4);
-                    if (masked) {
+            f32x4 v;
+            if (32 * i + 31 < H) {        // (compile-time: H is a multiple of 32) rows of h_prev
+                v = *reinterpret_cast<const f32x4*>(hsrc + row * 32 + c4);
+                v = first ? zero4 : v;
+            } else {
+                const int k = row - H, kc = k < I ? k : I - 1;
+                const int dd = kc / H, kk = kc - dd * H;
+                const float* s0 = xsrc0 + kc * 32 + c4;
+                const float* s1 = ysrc + (int64_t)((l - 1) * dirs + dd) * p.max_T * ts + kk * 32 + c4;
+                v = *reinterpret_cast<const f32x4*>(l == 0 ? s0 : s1);
+                if (masked) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = p.order[tile * SNN_TILE + c4 + e];
-                            if (o >= 0) v[e] = __fmul_rn(mask_in(p.mk, 0, p.n_curves, y.D, o, k), v[e]);
-                        }
-                    }
-                } else {
-                    const int dd = k / H, kk = k - dd * H;
-                    v = *reinterpret_cast<const f32x4*>(tape + ((int64_t)((l - 1) * dirs + dd) * p.max_T + t) * ts + 5 * H * 32 + kk * 32 + c4);
-                    if (masked) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = p.order[tile * SNN_TILE + c4 + e];
-                            if (o >= 0) v[e] = __fmul_rn(mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = p.order[tile * SNN_TILE + c4 + e];
+                        if (o >= 0 && k < I)
+                            v[e] = __fmul_rn(l == 0 ? mask_in(p.mk, 0, p.n_curves, y.D, o, k)
+                                                    : mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
                     }
                 }
-            } else if (row == H + I) {
-                v = f32x4{1.f, 1.f, 1.f, 1.f};
+                v = k < I ? v : (k == I ? one4 : zero4);
             }
             xv[i] = v;
         }
@@ -487,28 +502,64 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
         }
     };
     if (n_left > 0) {
+        enter_tile(tile);
         fetch(tile, t);
         commit();
     }
     __syncthreads();
+    const float* dGc = dGs + (32 * w + cl) * PAD + hf;
+    const float* xhc = xhs + cl * PAD + hf;
+#ifdef SNN_PROBE_DW   // clock64 probes of workgroup 0, wave 0: cycles per tile-step in each part of the loop
+    long long pc[5] = {0, 0, 0, 0, 0}; int pn = 0;
+#define PROBE(i) { const long long now_ = clock64(); pc[i] += now_ - pt_; pt_ = now_; }
+#else
+#define PROBE(i)
+#endif
     while (n_left > 0) {
+#ifdef SNN_PROBE_DW
+        long long pt_ = clock64(); ++pn;
+#endif
         const bool more = n_left > 1;
-        if (++t >= p.tile_T[tile]) { ++tile; t = 0; }      // (more => this is a tile-step of the chunk)
-        if (more) fetch(tile, t);
-        const float* dGc = dGs + (32 * w + cl) * PAD + hf;
-        const float* xhc = xhs + cl * PAD + hf;
+        if (more) {                                        // the next tile-step of the chunk
+            if (++t >= T_f) { ++tile; t = 0; enter_tile(tile); }
+            fetch(tile, t);
+        }
+        PROBE(0)
+        // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued
+        float an = dGc[0], bn[NTN];
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) bn[nt] = xhc[32 * nt * PAD];
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            const float a = dGc[2 * kk];
+            const float a = an;
+            float bc[NTN];
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xhc[32 * nt * PAD + 2 * kk], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTN; ++nt) bc[nt] = bn[nt];
+            if (kk + 1 < 16) {
+                an = dGc[2 * kk + 2];
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) bn[nt] = xhc[32 * nt * PAD + 2 * kk + 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[nt], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        PROBE(1)
         __syncthreads();
+        PROBE(2)
         if (more) commit();
+        PROBE(3)
         __syncthreads();
+        PROBE(4)
         --n_left;
     }
+#ifdef SNN_PROBE_DW
+    if (blockIdx.x == 0 && tid == 0 && pn > 0)
+        printf("bwd_dw<%d,%d> %d tile-steps: fetch %lld  mfma %lld  barrier %lld  commit %lld  barrier %lld cycles per tile-step\n", H, NTN, pn,
+               pc[0] / pn, pc[1] / pn, pc[2] / pn, pc[3] / pn, pc[4] / pn);
+#endif
+#undef PROBE
 
     // this lane's 16 gate rows: image row -> canonical row of the hidden-side (w_hh, b_hh) / input-side (w_ih, b_ih)
     // tensors; -1: no such row (GRU: group 2 is the input part of n, group 3 its hidden part; RNN: group 0 only)
@@ -549,16 +600,16 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
 // one instantiation per column-tile count that occurs for the hidden size (layer 0: D <= 78; layer >= 1: I = H or 2H)
 typedef void (*bwd_dw_t)(const Bwd2Params, int, int);
 template <int H, int N>
-static bwd_dw_t dw_pick()
+static bwd_dw_t dw_pick(bool masked)
 {
-    if constexpr (N <= 7) return bwd_dw_kernel<H, N, 2>;
-    else return bwd_dw_kernel<H, N, 1>;
+    if constexpr (N <= 7) return masked ? bwd_dw_kernel<H, N, 2, true> : bwd_dw_kernel<H, N, 2, false>;
+    else return masked ? bwd_dw_kernel<H, N, 1, true> : bwd_dw_kernel<H, N, 1, false>;
 }
 template <int H>
-static bwd_dw_t dw_kernel(int ntn)
+static bwd_dw_t dw_kernel(int ntn, bool masked)
 {
     switch (ntn) {
-#define SNN_DW(N) case N: if constexpr (32 * (N) >= H + 2 && 32 * ((N) - 1) < H + 2 * H + 1) return dw_pick<H, N>(); else return nullptr;
+#define SNN_DW(N) case N: if constexpr (32 * (N) >= H + 2 && 32 * ((N) - 1) < H + 2 * H + 1) return dw_pick<H, N>(masked); else return nullptr;
         SNN_DW(2) SNN_DW(3) SNN_DW(4) SNN_DW(5) SNN_DW(6) SNN_DW(7) SNN_DW(8) SNN_DW(9) SNN_DW(10) SNN_DW(11) SNN_DW(12) SNN_DW(13)
 #undef SNN_DW
     }
@@ -805,6 +856,7 @@ int64_t snn_bwd_big_workspace_bytes(const SnnLayout& y, int n_tiles, int max_T)
 
 bool snn_rec16_supported(const SnnLayout& y);                          // snn_rec16.hip
 int snn_launch_bwd_rec16(const Bwd2Params& p, int l, hipStream_t st);
+bool snn_launch_bwd_dx_lds(const Bwd2Params& p, int l, hipStream_t st);   // snn_bwd_dx.hip
 
 // side stream + events of the overlapped weight-gradient GEMMs (small batches), one set per host thread and device
 struct SideStream { int dev = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
@@ -854,7 +906,11 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
         if (rec16) snn_launch_bwd_rec16(p, l, st);
         else hipLaunchKernelGGL((bwd_rec_kernel<H, CELL>), dim3(p.n_tiles * y.dirs), dim3(256), lds_rec, st, p, l);
         HIP_CHECK(hipGetLastError());
-        if (l > 0) {
+        // chip-filling batches of wide layers: the LDS-staged kernel of snn_bwd_dx.hip (SNN_DX_LDS=0: A/B, tests)
+        const char* dxl = getenv("SNN_DX_LDS");
+        if (l > 0 && !small && !(dxl && dxl[0] == '0') && snn_launch_bwd_dx_lds(p, l, st)) {
+            HIP_CHECK(hipGetLastError());
+        } else if (l > 0) {
             const int mtx = y.dirs * H / 32, mtxw = std::min(mtx, 4);
             // time steps per wave: 4 * mtxw / 4 fills a 4-step workgroup (fewest operand loads); 1 for small batches
             int tsw = mtx == 1 ? 1 : mtx == 2 ? 2 : 4;
@@ -866,7 +922,7 @@ static int launch_big(const Bwd2Params& p0, const Bwd2Geom& g, hipStream_t st)
             HIP_CHECK(hipGetLastError());
         }
         const int ntn = (H + y.I[l] + 1 + 31) / 32;
-        bwd_dw_t dw = dw_kernel<H>(ntn);
+        bwd_dw_t dw = dw_kernel<H>(ntn, p.mk.mode != SNN_MASK_NONE);
         if (!dw) { snn_set_error("no weight-gradient kernel for H=%d with input width %d", H, y.I[l]); return SNN_ERR_UNSUPPORTED; }
         const size_t lds_dw = sizeof(float) * ((size_t)128 * PAD + (size_t)ntn * 32 * PAD);
         HIP_CHECK(hipFuncSetAttribute((const void*)dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw));

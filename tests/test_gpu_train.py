@@ -770,6 +770,36 @@ def test_h128_backward_takes_half_tiles_at_every_size():
     assert not torch.equal(res[None][2], res["0"][2])    # (another MFMA shape: the two paths are different kernels)
 
 
+@pytest.mark.parametrize("D,H,L,bidir,masked,n,T", [
+    (24, 64, 2, True, None, 4200, 7),        # 4 output tiles: one per wave
+    (26, 128, 2, True, "step", 2100, 6),     # 8 output tiles: two per wave; per-step between-layer masks in the epilogue
+    (24, 128, 3, False, None, 4200, 5),      # unidirectional H = 128: 4 output tiles, two layers with a layer below
+    (78, 128, 2, True, None, 4130, 9),       # T not a multiple of the 4 steps of a workgroup, ragged last tile
+])
+def test_lds_staged_dx_kernel_is_bit_identical(D, H, L, bidir, masked, n, T):
+    """bwd_dx_lds_kernel (snn_bwd_dx.hip: dG staged through LDS once per workgroup, all output tiles of a (tile, 4 steps)
+    item at once) issues the same products in the same order as bwd_dx_kernel (SNN_DX_LDS=0): the gradients of a
+    chip-filling batch are equal bit for bit."""
+    import os
+    from supernnova_amd import engine as E
+    cfg = E.Config(D, H, L, bidir, 3, "mean")
+
+    def masks_fn(plan):
+        return E.Masks(mode=2, which=4 | 8, dropout=0.2, seed=81, mid_T=plan.max_T) if masked == "step" else None
+    res = {}
+    for v in ("0", None):
+        if v is not None:
+            os.environ["SNN_DX_LDS"] = v
+        try:
+            plan, out, _ = _forward_train_variants(cfg, n, T, masks_fn, variants=("0",))
+        finally:
+            os.environ.pop("SNN_DX_LDS", None)
+        assert plan.n_tiles * cfg.dirs * 2 > 256      # beyond the small-batch rule: the large-batch kernels run
+        res[v] = out[0]
+    assert torch.equal(res["0"][2], res[None][2])
+    assert float(res[None][2].abs().max()) > 0
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tag", ["t13", "t300"])
 def test_train_step_at_the_elasticc_shape_vs_reference(tag, fused):
