@@ -443,48 +443,43 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
     // Software pipeline over the chunk's tile-steps: the operands of the next tile-step are fetched into registers
     // while the MFMAs of the current one run from LDS (an un-overlapped fetch was ~60 % of the kernel's time).
     f32x4 gv[4], xv[NTN];   // 128 dG rows and NTN * 32 [h_prev | x_t | 1 | 0] rows, 8 float4 per row, 256 threads
-    // Branch-free: every load is unconditional at a clamped address and rows without a source are chosen by selects
-    // afterwards.  With the rows' cases written as branches the compiler put s_waitcnt vmcnt(0) at the joins (a register
-    // written by a load on one path and by a move on the other), so each load of a fetch waited for the one before it:
-    // clock64 probes read 5 200 cycles per tile-step for the 17 loads of H = 128 / layer 1 beside 13 300 cycles of MFMAs.
-    auto fetch = [&](int tile, int t) __attribute__((always_inline)) {
-        const float* src = dG_f + (int64_t)t * 4 * H * 32;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
-            gv[i] = *reinterpret_cast<const f32x4*>(src + row * 32 + c4);
-        }
+    // Branch-free: every load is unconditional at a clamped address, and what depends on the loaded VALUES -- zeros for
+    // h_prev at a direction's first step, the ones row, the padding rows, the dropout masks -- is applied by commit(),
+    // after the MFMAs the fetch runs beside.  With the rows' cases written as branches the compiler put s_waitcnt
+    // vmcnt(0) at the joins, and with selects inside the fetch it waited for the loads right there: clock64 probes read
+    // 5 200 / 3 300 cycles per tile-step for the 17 loads of H = 128 / layer 1 in front of 13 300 cycles of MFMAs.
+    bool first_c = false;     // of the fetched tile-step, for commit()
+    int tile_c = 0, t_c = 0;
+    // The 4 + NTN loads of a fetch are dealt out over the 16 k-steps of the MFMA block (fetch_piece): issued in one
+    // burst at the top of the tile-step, the four waves' 64-address instructions queued at the compute unit's one
+    // address unit for ~2 200 cycles (H = 128, layer 1) before the first MFMA could issue.
+    constexpr int NP = 4 + NTN;
+    const float *src_f = nullptr, *hsrc_f = nullptr, *xsrc0_f = nullptr, *ysrc_f = nullptr;
+    auto fetch_setup = [&](int tile, int t) __attribute__((always_inline)) {
+        src_f = dG_f + (int64_t)t * 4 * H * 32;
         const bool first = d == 0 ? t == 0 : t == T_f - 1;   // first processed step of this direction: h_prev = 0
         const int tp = first ? t : (d == 0 ? t - 1 : t + 1);
-        const float* hsrc = tape_f + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32;
-        const float* xsrc0 = x_f + (int64_t)t * y.Dp * 32;                       // layer 0: packed input rows of step t
-        const float* ysrc = tape_f + (int64_t)t * ts + 5 * H * 32;               // layer > 0: outputs of the layer below
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int i = 0; i < NTN; ++i) {
+        hsrc_f = tape_f + ((int64_t)ld * p.max_T + tp) * ts + 5 * H * 32;
+        xsrc0_f = x_f + (int64_t)t * y.Dp * 32;                       // layer 0: packed input rows of step t
+        ysrc_f = tape_f + (int64_t)t * ts + 5 * H * 32;               // layer > 0: outputs of the layer below
+        first_c = first; tile_c = tile; t_c = t;
+    };
+    auto fetch_piece = [&](int j) __attribute__((always_inline)) {
+        if (j < 4) {
+            const int f = tid + j * 256, row = f >> 3, c4 = (f & 7) * 4;
+            gv[j] = *reinterpret_cast<const f32x4*>(src_f + row * 32 + c4);
+        } else {
+            const int i = j - 4;
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
-            f32x4 v;
             if (32 * i + 31 < H) {        // (compile-time: H is a multiple of 32) rows of h_prev
-                v = *reinterpret_cast<const f32x4*>(hsrc + row * 32 + c4);
-                v = first ? zero4 : v;
+                xv[i] = *reinterpret_cast<const f32x4*>(hsrc_f + row * 32 + c4);
             } else {
                 const int k = row - H, kc = k < I ? k : I - 1;
                 const int dd = kc / H, kk = kc - dd * H;
-                const float* s0 = xsrc0 + kc * 32 + c4;
-                const float* s1 = ysrc + (int64_t)((l - 1) * dirs + dd) * p.max_T * ts + kk * 32 + c4;
-                v = *reinterpret_cast<const f32x4*>(l == 0 ? s0 : s1);
-                if (masked) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = p.order[tile * SNN_TILE + c4 + e];
-                        if (o >= 0 && k < I)
-                            v[e] = __fmul_rn(l == 0 ? mask_in(p.mk, 0, p.n_curves, y.D, o, k)
-                                                    : mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t, o, k), v[e]);
-                    }
-                }
-                v = k < I ? v : (k == I ? one4 : zero4);
+                const float* s0 = xsrc0_f + kc * 32 + c4;
+                const float* s1 = ysrc_f + (int64_t)((l - 1) * dirs + dd) * p.max_T * ts + kk * 32 + c4;
+                xv[i] = *reinterpret_cast<const f32x4*>(l == 0 ? s0 : s1);
             }
-            xv[i] = v;
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
@@ -494,16 +489,35 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
 #pragma unroll
             for (int e = 0; e < 4; ++e) dGs[row * PAD + c4 + e] = gv[i][e];
         }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < NTN; ++i) {
             const int f = tid + i * 256, row = f >> 3, c4 = (f & 7) * 4;
+            f32x4 v = xv[i];
+            if (32 * i + 31 < H) {
+                v = first_c ? zero4 : v;
+            } else {
+                const int k = row - H;
+                if (masked) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = xv[i][e];
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = p.order[tile_c * SNN_TILE + c4 + e];
+                        if (o >= 0 && k < I)
+                            v[e] = __fmul_rn(l == 0 ? mask_in(p.mk, 0, p.n_curves, y.D, o, k)
+                                                    : mask_mid(p.mk, 0, y.L, p.n_curves, dirs * H, l - 1, t_c, o, k), v[e]);
+                    }
+                }
+                v = k < I ? v : (k == I ? one4 : zero4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xhs[row * PAD + c4 + e] = v[e];
         }
     };
     if (n_left > 0) {
         enter_tile(tile);
-        fetch(tile, t);
+        fetch_setup(tile, t);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) fetch_piece(j);
         commit();
     }
     __syncthreads();
@@ -522,8 +536,8 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
         const bool more = n_left > 1;
         if (more) {                                        // the next tile-step of the chunk
             if (++t >= T_f) { ++tile; t = 0; enter_tile(tile); }
-            fetch(tile, t);
         }
+        fetch_setup(tile, t);      // (the chunk's last tile-step fetches itself again: no branch in the MFMA block)
         PROBE(0)
         // operands of k-step kk + 1 are read from LDS before the MFMAs of k-step kk are issued
         float an = dGc[0], bn[NTN];
@@ -542,7 +556,14 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[nt], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTN; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[nt], acc[nt], 0, 0, 0);
+                if (nt == 0) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j)
+                        if ((j * 16) / NP == kk) fetch_piece(j);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         PROBE(1)
@@ -599,11 +620,14 @@ __global__ void __launch_bounds__(256, OCC) bwd_dw_kernel(const Bwd2Params p, in
 
 // one instantiation per column-tile count that occurs for the hidden size (layer 0: D <= 78; layer >= 1: I = H or 2H)
 typedef void (*bwd_dw_t)(const Bwd2Params, int, int);
+#ifndef SNN_DW_OCC
+#define SNN_DW_OCC(N) ((N) <= 3 ? 4 : (N) <= 7 ? 2 : 1)   // workgroups per compute unit (the grid comes in rounds of 256 x 2^k slots: bwd2_geom)
+#endif
 template <int H, int N>
 static bwd_dw_t dw_pick(bool masked)
 {
-    if constexpr (N <= 7) return masked ? bwd_dw_kernel<H, N, 2, true> : bwd_dw_kernel<H, N, 2, false>;
-    else return masked ? bwd_dw_kernel<H, N, 1, true> : bwd_dw_kernel<H, N, 1, false>;
+    constexpr int OCC = SNN_DW_OCC(N);
+    return masked ? bwd_dw_kernel<H, N, OCC, true> : bwd_dw_kernel<H, N, OCC, false>;
 }
 template <int H>
 static bwd_dw_t dw_kernel(int ntn, bool masked)
