@@ -322,7 +322,7 @@ bool snn_rec16_supported(const SnnLayout& y);
 int snn_launch_fwd_rec16(const SnnLayout& y, const FwdParams& p, int l, float* head_part, const float* gx, hipStream_t st);
 const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
-fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train);  // snn_forward_big.hip
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train, bool masked);  // snn_forward_big.hip
 fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs, bool masked);      // snn_forward_pair.hip
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
@@ -345,8 +345,9 @@ static const FwdEntry* find_fwd(const SnnLayout& y)
         return &ent;
     }
     // hidden sizes whose weights do not fit the register file: two-pass kernel
-    if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, false)) {
-        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, true), true, nullptr,
+    if (fwd_kernel_t fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, false, false)) {
+        ent = FwdEntry{y.H, y.KKI[0], y.dirs, fn, snn_big_kernel(y.H, y.KKI[0], y.dirs, false, true),
+                       snn_big_kernel(y.H, y.KKI[0], y.dirs, true, true), true, nullptr,
                        snn_big_rec_kernel(y.H, y.KKI[0], y.dirs)};
         return &ent;
     }
@@ -744,6 +745,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     const bool masked = masks && masks->mode != SNN_MASK_NONE;
     fwd_kernel_t fn = train ? e->fn_train : masked ? e->fn_masked : e->fn;
+    if (e->big && train && !masked) fn = snn_big_kernel(y.H, y.KKI[0], y.dirs, true, false);   // no mask code in the kernel
     if (!fn) { snn_set_error("no %s kernel for H=%d cell=%d", train ? "training" : "masked", y.H, y.cell); return SNN_ERR_UNSUPPORTED; }
     if (e->big && !train && masked && masks->mid_T != 1) { snn_set_error("H=%d kernels take locked between-layer masks only", y.H); return SNN_ERR_UNSUPPORTED; }
     // un-masked inference: two tiles per workgroup, software-pipelined (snn_forward_pair.hip)

@@ -20,7 +20,8 @@
 
 // One (layer, direction) phase.  TP = row tiles per wave handled by one input pass.
 // GX: pass 1 was done by fwd_gx_kernel (snn_fwd_gx.hip) for all tiles at once; `gx` is this (tile, direction)'s block.
-template <int H, int KKI, int DIRS, bool FIRST, int TP, bool TRAIN, bool GX = false>
+// MASKED = false is launched for models without dropout masks only: no Philox code in the kernel at all.
+template <int H, int KKI, int DIRS, bool FIRST, int TP, bool TRAIN, bool MASKED, bool GX = false>
 __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, int l, int d, int k_A, int k_bias,
                                           int k_head_w, float* xin, float* hb, float* part, float* logit,
                                           float* mlds, float* gx)
@@ -31,7 +32,7 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     static_assert(RT % TP == 0, "tiles per pass must divide the tiles per wave");
     const FwdParams& y = p;
     const MaskP& mk = p.mk;
-    const bool masked = mk.mode != SNN_MASK_NONE;
+    const bool masked = MASKED && mk.mode != SNN_MASK_NONE;
     const int ld = l * DIRS + d;
     const bool last_layer = l == y.L - 1;
     const int T = c.T;
@@ -42,6 +43,14 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     float* tape_ld = TRAIN ? c.tape + (int64_t)ld * p.max_T * tape_step_floats(H) : nullptr;
     const bool mid_step = masked && mk.mid_T > 1;   // per-step between-layer mask (torch.nn.LSTM dropout in train mode)
 
+    // Staging of x_t (or the layer below's y_t) is branch-free: a thread beyond the image duplicates its last float4
+    // (same value to the same LDS address) and the step after the last re-stages the last one.  With the loads under
+    // `if (f < NF4)` / `if (more)` the compiler put s_waitcnt vmcnt at the joins, so every step of the input pass waited
+    // for the Gx stores of the step before it and for its own staging loads (20.5 ms of the 34.4 ms forward of 8192
+    // curves x 300 steps, for 57 % of its FLOPs).
+    int fi[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) fi[i] = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
     // input-mask registers of the staging threads (layer 0, variational)
     float min_[NPT][4];
 #pragma unroll
@@ -51,57 +60,48 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
     if (!GX && masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const int k = f >> 3, c4 = (f & 7) * 4;
+            const int f = fi[i];
+            const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                    if (o >= 0) {
-                        if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
-                        else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                if (o >= 0) {
+                    if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
+                    else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
                 }
             }
         }
     }
-    auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const float* src;
-                if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
-                else {
-                    const int dd = f / (H * 8), ff = f - dd * (H * 8);
-                    if (TRAIN) src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
-                    else src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
-                }
-                pre[i] = *reinterpret_cast<const f32x4*>(src);
-            }
+    auto load_piece = [&](int i, int t) __attribute__((always_inline)) -> f32x4 {
+        const int f = fi[i];
+        const float* src;
+        if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
+        else {
+            const int dd = f / (H * 8), ff = f - dd * (H * 8);
+            if (TRAIN) src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
+            else src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
         }
+        return *reinterpret_cast<const f32x4*>(src);
     };
-    auto store_step = [&](float* dst, const f32x4 (&pre)[NPT], int t) {
+    auto store_step = [&](float* dst, const f32x4 (&pre)[NPT], int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                f32x4 v = pre[i];
-                if (FIRST || TRAIN) {
-                    if (!FIRST && mid_step) {
-                        const int k = f >> 3, c4 = (f & 7) * 4;
+            const int f = fi[i];
+            f32x4 v = pre[i];
+            if (MASKED && (FIRST || TRAIN)) {
+                if (!FIRST && mid_step) {
+                    const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                            if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                        if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
                 }
-                *reinterpret_cast<f32x4*>(dst + f * 4) = v;
             }
+            *reinterpret_cast<f32x4*>(dst + f * 4) = v;
         }
     };
 
@@ -124,21 +124,24 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
         }
         {
             f32x4 pre[NPT];
-            load_step(0, pre);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) pre[i] = load_piece(i, 0);
             store_step(xin, pre, 0);
         }
         lds_barrier();
+        static_assert(NPT <= KKI, "one staging load behind each of the first k-steps");
         for (int t = 0; t < T; ++t) {
             const int cur = t & 1;
+            const int tn = t + 1 < T ? t + 1 : t;
             f32x4 pre[NPT];
-            const bool more = t + 1 < T;
-            if (more) load_step(t + 1, pre);
             f32x16 acc[TP];
 #pragma unroll
             for (int r = 0; r < TP; ++r) acc[r] = binit[r];
             const float* xc = xin + cur * XIN_STRIDE + c.lane;
             // B operands are read from LDS BA k-steps ahead of their MFMAs (sched_barrier keeps the order): with one or
-            // two MFMAs per k-step the LDS latency is otherwise exposed at every k-step
+            // two MFMAs per k-step the LDS latency is otherwise exposed at every k-step.  The staging loads of the next
+            // step are dealt out one per k-step behind the first MFMAs (issued in one burst, the four waves' loads queue
+            // at the compute unit's one address unit in front of the MFMAs).
             constexpr int BA = 4;
             float bq[BA];
 #pragma unroll
@@ -149,15 +152,17 @@ __device__ __forceinline__ void big_phase(const FwdParams& p, const ItemCtx& c, 
                 if (kk + BA < KKI) bq[kk % BA] = xc[(kk + BA) * 64];
 #pragma unroll
                 for (int r = 0; r < TP; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[r][kk], b, acc[r], 0, 0, 0);
+                if (kk < NPT) pre[kk] = load_piece(kk, tn);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // Gx of this step: 16-byte words [tile][gate q][lane][unit 0..3] (4 stores per row tile instead of 16)
 #pragma unroll
             for (int r = 0; r < TP; ++r) {
-                float* g = gx + ((int64_t)t * NWT + (c.w * RT + r0 + r)) * 1024 + c.lane;
+                f32x4* g = reinterpret_cast<f32x4*>(gx + ((int64_t)t * NWT + (c.w * RT + r0 + r)) * 1024) + c.lane;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) g[i * 64] = acc[r][i];
+                for (int q = 0; q < 4; ++q) g[q * 64] = f32x4{acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]};
             }
-            if (more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, t + 1);
+            store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
             lds_barrier();
         }
     }
@@ -183,14 +188,29 @@ pass2:
     }
     // locked between-layer mask of this lane's units, parked in LDS: mlds[unit][curve] (1.0 without masks: the y
     // stores below multiply unconditionally, x * 1.0f == x bit for bit)
-    const bool use_mid = masked && !last_layer && !TRAIN;
-    if (!last_layer && !TRAIN) {
+    if (MASKED && !last_layer && !TRAIN) {
         for (int idx = c.tid; idx < H * 32; idx += NT) {
             const int j = idx >> 5, cc = idx & 31;
             const int o = p.order[c.tile * SNN_TILE + cc];
-            mlds[idx] = (use_mid && o >= 0) ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, o, d * H + j) : 1.0f;
+            mlds[idx] = (masked && o >= 0) ? mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, o, d * H + j) : 1.0f;
         }
     }
+    // Gx[t] of row tile r into its accumulator: fwd_gx_kernel's layout [i][lane] (GX) or pass 1's 16-byte words
+    auto load_gx = [&](int t, int r, f32x16& a) __attribute__((always_inline)) {
+        const float* g = gx + ((int64_t)t * NWT + (c.w * RT + r)) * 1024;
+        if (GX) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = g[i * 64 + c.lane];
+        } else {
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(g) + c.lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = g4[q * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[4 * q + e] = v[e];
+            }
+        }
+    };
     float cst[RT][4], hst[RT][4], hsum[RT][4];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -203,11 +223,7 @@ pass2:
     {
         const int t0 = d == 0 ? 0 : T - 1;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float* g = gx + ((int64_t)t0 * NWT + (c.w * RT + r)) * 1024 + c.lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
-        }
+        for (int r = 0; r < RT; ++r) load_gx(t0, r, acc[r]);
     }
     lds_barrier();
     // The step body is ONE straight-line block: the "still inside the curve" selects are v_cndmask on a ballot (a C++
@@ -255,11 +271,7 @@ pass2:
             }
             // the next step's Gx for this tile goes straight into the now-free accumulator
 #ifndef SNN_ABL_BIG_NOGX   // (timing ablation only, results are wrong: no Gx reload)
-            {
-                const float* g = gx + ((int64_t)tn * NWT + (c.w * RT + r)) * 1024 + c.lane;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[r][i] = g[i * 64];
-            }
+            load_gx(tn, r, acc[r]);
 #endif
         }
         if (last_layer) {
@@ -273,7 +285,7 @@ pass2:
                 const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
                 float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) yo[u * 32] = __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[r][u]);
+                for (int u = 0; u < 4; ++u) yo[u * 32] = MASKED ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[r][u]) : outv[r][u];
             }
         }
         lds_barrier();
@@ -318,7 +330,7 @@ pass2:
     __syncthreads();
 }
 
-template <int H, int KKI0, int DIRS, bool TRAIN>
+template <int H, int KKI0, int DIRS, bool TRAIN, bool MASKED>
 __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
 {
     constexpr int NT = 256;
@@ -370,11 +382,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
             for (int d = 0; d < DIRS; ++d) {
                 if (l == 0) {
                     const int kA = d * BLK0;
-                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 2), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
+                    big_phase<H, KKI0, DIRS, true, (KKI0 <= 48 ? H / 32 : 2), TRAIN, MASKED>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64,
                                                                             k_head_w, xin, hb, part, logit, mlds, gx);
                 } else {
                     const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 2), TRAIN>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
+                    big_phase<H, KKI1, DIRS, false, (KKI1 <= 48 ? H / 32 : 2), TRAIN, MASKED>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64,
                                                                              k_head_w, xin, hb, part, logit, mlds, gx);
                 }
             }
@@ -443,11 +455,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_rec_kernel(const FwdParam
     __syncthreads();
     if (l == 0) {
         const int kA = d * BLK0;
-        big_phase<H, KKI0, DIRS, true, 1, true, true>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64, k_head_w, nullptr, hb, part,
+        big_phase<H, KKI0, DIRS, true, 1, true, true, true>(p, c, l, d, kA, kA + NWT * (KKI0 + H / 2) * 64, k_head_w, nullptr, hb, part,
                                                       logit, mlds, gxb);
     } else {
         const int kA = DIRS * BLK0 + ((l - 1) * DIRS + d) * BLK1;
-        big_phase<H, KKI1, DIRS, false, 1, true, true>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64, k_head_w, nullptr, hb, part,
+        big_phase<H, KKI1, DIRS, false, 1, true, true, true>(p, c, l, d, kA, kA + NWT * (KKI1 + H / 2) * 64, k_head_w, nullptr, hb, part,
                                                        logit, mlds, gxb);
     }
     if (y.pool == SNN_POOL_STANDARD || l == y.L - 1) {   // per-wave head partials of this phase, for head_combine_kernel
@@ -458,8 +470,11 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_rec_kernel(const FwdParam
 
 // ---- registry hooks used by snn_forward.hip -------------------------------------------------------
 typedef void (*fwd_kernel_t)(const FwdParams);
-#define BIG_PICK(K, Dd) if (KKI0 == K && dirs == Dd) return train ? lstm_fwd_big_kernel<128, K, Dd, true> : lstm_fwd_big_kernel<128, K, Dd, false>
-fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train)
+#define BIG_PICK(K, Dd)                                                                                                   \
+    if (KKI0 == K && dirs == Dd)                                                                                          \
+        return train ? (masked ? lstm_fwd_big_kernel<128, K, Dd, true, true> : lstm_fwd_big_kernel<128, K, Dd, true, false>)  \
+                     : (masked ? lstm_fwd_big_kernel<128, K, Dd, false, true> : lstm_fwd_big_kernel<128, K, Dd, false, false>)
+fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train, bool masked)
 {
     if (H != 128) return nullptr;
     BIG_PICK(12, 2); BIG_PICK(13, 2); BIG_PICK(24, 2); BIG_PICK(38, 2); BIG_PICK(39, 2);   // D <= 24, 26, 48, 76, 78
