@@ -51,24 +51,31 @@ __global__ void __launch_bounds__(256, 2) bwd_dx_lds_kernel(const Bwd2Params p, 
 
     f32x4 bst[DX_TS];            // this thread's 16 bytes of each step's chunk image
     float an[MPW][DX_KC];        // A operands of the next chunk
-    auto fetch = [&](int c) __attribute__((always_inline)) {
+    // the DX_TS + MPW * DX_KC loads of a chunk, dealt out one per k-step (and the rest behind the first MFMAs): issued in
+    // one burst they queue at the compute unit's one address unit in front of the chunk's MFMAs
+    const float *Bf = nullptr, *Af = nullptr;
+    auto fetch_setup = [&](int c) __attribute__((always_inline)) {
         const int d = c / NCD, kc = c - d * NCD;
         const int ld = l * dirs + d;
-        const float* B = p.dG + ((int64_t)tile * dirs + d) * p.max_T * (4 * H * 32) + kc * (DX_KC * 64) + tid * 4;
-#pragma unroll
-        for (int s = 0; s < DX_TS; ++s) bst[s] = *reinterpret_cast<const f32x4*>(B + (int64_t)tc[s] * (4 * H * 32));
-        const float* A = p.WT + p.wt_ih[ld] + kc * (DX_KC * 64) + lane;
-#pragma unroll
-        for (int m = 0; m < MPW; ++m)
-#pragma unroll
-            for (int k = 0; k < DX_KC; ++k) an[m][k] = A[(int64_t)(w + 4 * m) * 2 * H * 64 + k * 64];
+        Bf = p.dG + ((int64_t)tile * dirs + d) * p.max_T * (4 * H * 32) + kc * (DX_KC * 64) + tid * 4;
+        Af = p.WT + p.wt_ih[ld] + kc * (DX_KC * 64) + lane;
+    };
+    constexpr int NPC = DX_TS + MPW * DX_KC;     // pieces per chunk
+    auto fetch_piece = [&](int j) __attribute__((always_inline)) {
+        if (j < DX_TS) bst[j] = *reinterpret_cast<const f32x4*>(Bf + (int64_t)tc[j] * (4 * H * 32));
+        else {
+            const int m = (j - DX_TS) / DX_KC, k = (j - DX_TS) % DX_KC;
+            an[m][k] = Af[(int64_t)(w + 4 * m) * 2 * H * 64 + k * 64];
+        }
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < DX_TS; ++s) *reinterpret_cast<f32x4*>(&bs[buf][s][tid * 4]) = bst[s];
     };
 
-    fetch(0);
+    fetch_setup(0);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) fetch_piece(j);
     commit(0);
     float ac[MPW][DX_KC];
 #pragma unroll
@@ -76,9 +83,10 @@ __global__ void __launch_bounds__(256, 2) bwd_dx_lds_kernel(const Bwd2Params p, 
 #pragma unroll
         for (int k = 0; k < DX_KC; ++k) ac[m][k] = an[m][k];
     __syncthreads();
+    constexpr int PPK = (NPC + DX_KC - 1) / DX_KC;   // pieces behind each k-step
     for (int c = 0; c < NC; ++c) {
         const int buf = c & 1;
-        fetch(c + 1 < NC ? c + 1 : c);
+        fetch_setup(c + 1 < NC ? c + 1 : c);
         __builtin_amdgcn_sched_barrier(0);
         const float* bc = &bs[buf][0][lane];
 #pragma unroll
@@ -89,7 +97,10 @@ __global__ void __launch_bounds__(256, 2) bwd_dx_lds_kernel(const Bwd2Params p, 
 #pragma unroll
             for (int m = 0; m < MPW; ++m)
 #pragma unroll
-                for (int s = 0; s < DX_TS; ++s) acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][k], b[s], acc[m][s], 0, 0, 0);
+                for (int s = 0; s < DX_TS; ++s) {
+                    acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m][k], b[s], acc[m][s], 0, 0, 0);
+                    if (m == 0 && s < PPK && k * PPK + s < NPC) fetch_piece(k * PPK + s);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
         commit(buf ^ 1);

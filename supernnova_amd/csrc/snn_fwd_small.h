@@ -74,6 +74,12 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         for (int u = 0; u < 4; ++u)
             mmid[u] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, c.orig, d * H + j0 + u);
     }
+    // Staging is branch-free: a thread beyond the image duplicates its last float4 (same value to the same LDS address)
+    // and the step after the last re-stages the last one -- loads under `if (f < NF4)` / `if (more)` made the compiler
+    // put s_waitcnt vmcnt at the joins (snn_forward_big.hip has the measurement).
+    int fi[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) fi[i] = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
     // mask registers of the staging threads: layer 0 input mask, or (TRAIN) the between-layer mask
     float min_[NPT][4];
 #pragma unroll
@@ -83,16 +89,14 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
     if (!GX && masked && (FIRST || (TRAIN && !mid_step))) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const int k = f >> 3, c4 = (f & 7) * 4;
+            const int f = fi[i];
+            const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                    if (o >= 0) {
-                        if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
-                        else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                if (o >= 0) {
+                    if (FIRST) { if (k < y.D) min_[i][e] = mask_in(mk, c.s, p.n_curves, y.D, o, k); }
+                    else min_[i][e] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, 0, o, k);
                 }
             }
         }
@@ -107,45 +111,41 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
                                         : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * H * 32;
     float* tape_ld = TRAIN ? c.tape + (int64_t)ld * p.max_T * tape_step_floats(H) : nullptr;
 
-    auto load_step = [&](int t, f32x4 (&pre)[NPT]) {
+    auto load_step = [&](int t, f32x4 (&pre)[NPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                const float* src;
-                if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
-                else {
-                    const int dd = f / (H * 8), ff = f - dd * (H * 8);
-                    if (TRAIN)
-                        src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
-                    else
-                        src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
-                }
-                pre[i] = *reinterpret_cast<const f32x4*>(src);
+            const int f = fi[i];
+            const float* src;
+            if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
+            else {
+                const int dd = f / (H * 8), ff = f - dd * (H * 8);
+                if (TRAIN)
+                    src = in0 + ((int64_t)((l - 1) * DIRS + dd) * p.max_T + t) * tape_step_floats(H) + 5 * H * 32 + ff * 4;
+                else
+                    src = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + ff * 4;
             }
+            pre[i] = *reinterpret_cast<const f32x4*>(src);
         }
     };
-    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT], int t) {
+    auto store_step = [&](float* dstbuf, const f32x4 (&pre)[NPT], int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int f = c.tid + i * NT;
-            if (f < NF4) {
-                f32x4 v = pre[i];
-                if (FIRST || TRAIN) {
-                    if (!FIRST && mid_step) {
-                        const int k = f >> 3, c4 = (f & 7) * 4;
+            const int f = fi[i];
+            f32x4 v = pre[i];
+            if (MASKED && (FIRST || TRAIN)) {
+                if (!FIRST && mid_step) {
+                    const int k = f >> 3, c4 = (f & 7) * 4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int o = p.order[c.tile * SNN_TILE + c4 + e];
-                            if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = p.order[c.tile * SNN_TILE + c4 + e];
+                        if (o >= 0) v[e] = __fmul_rn(mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l - 1, t, o, k), v[e]);
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fmul_rn(min_[i][e], v[e]);
                 }
-                *reinterpret_cast<f32x4*>(dstbuf + f * 4) = v;
             }
+            *reinterpret_cast<f32x4*>(dstbuf + f * 4) = v;
         }
     };
 
@@ -174,16 +174,14 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         const int cur = step & 1;
         f32x4 pre[NPT];
         const bool more = step + 1 < T;
-        const int tn = d == 0 ? t + 1 : t - 1;
-        if (!GX && more) load_step(tn, pre);
+        const int tn = more ? (d == 0 ? t + 1 : t - 1) : t;      // the step after the last: this one again (unused)
+        if (!GX) load_step(tn, pre);
 
         f32x16 acc;
         if (GX) {
             acc = gxn;
-            if (more) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];
-            }
+            for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];   // (after the last step: unused)
             // tape row of the step before: staged in LDS by its cell update (below), written here as 16-byte words --
             // 6 store instructions per thread beside this step's MFMAs instead of 24 4-byte ones between the cell
             // update and the barrier (with one workgroup per compute unit nothing else hides their issue time)
@@ -279,7 +277,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             }
             }
         }
-        if (!GX && more) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
+        if (!GX) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
         lds_barrier();
     }
     if (GX && TRAIN && T > 0) {      // the last step's tape row (its staging writes are behind the loop's closing barrier)

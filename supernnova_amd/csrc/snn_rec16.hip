@@ -259,9 +259,17 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
             dfm[i][1] = v[1] * inv_len[1];
         }
     }
-    f32x2 n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cn[UPT], n_dy[UPT];
+    // Everything a step reads from the tape is fetched one step ahead by unconditional loads at clamped addresses (a
+    // load under `if (step > 0)` / `dy ? .. : ..` makes the compiler wait at the join): the gates and dy of step t, and
+    // the cell state its predecessor left (c_{t-1}: needed by the forget-gate gradient of step t).  A step's own c is
+    // the predecessor state fetched for the step processed before it, carried in a register -- fetched together with
+    // the other rows of step t - 1, it was awaited in the middle of step t, a trip to memory on the chain of every step.
+    f32x2 n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cp[UPT], n_dy[UPT], ccur[UPT];
+    const float* dyp = dy ? dy : tape_ld;      // (no dy: any readable address, the values are not used)
     auto fetch = [&](int t) __attribute__((always_inline)) {
         const float* tq = tape_ld + (int64_t)t * ts + cg2;
+        const int tpp = d == 0 ? (t > 0 ? t - 1 : 0) : (t + 1 < T ? t + 1 : T - 1);
+        const float* tc = tape_ld + (int64_t)tpp * ts + cg2;
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             const int j = jg + JS * i;
@@ -269,22 +277,28 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
             n_fg[i] = *reinterpret_cast<const f32x2*>(tq + (1 * H + j) * 32);
             n_gg[i] = *reinterpret_cast<const f32x2*>(tq + (2 * H + j) * 32);
             n_og[i] = *reinterpret_cast<const f32x2*>(tq + (3 * H + j) * 32);
-            n_cn[i] = *reinterpret_cast<const f32x2*>(tq + (4 * H + j) * 32);
-            n_dy[i] = dy ? *reinterpret_cast<const f32x2*>(dy + (int64_t)t * H * 32 + j * 32 + cg2) : zero2;
+            n_cp[i] = *reinterpret_cast<const f32x2*>(tc + (4 * H + j) * 32);
+            n_dy[i] = *reinterpret_cast<const f32x2*>(dyp + (int64_t)t * H * 32 + j * 32 + cg2);
         }
     };
-    if (T > 0) fetch(d == 0 ? T - 1 : 0);
+    if (T > 0) {
+        const int tl = d == 0 ? T - 1 : 0;
+        fetch(tl);
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) ccur[i] = *reinterpret_cast<const f32x2*>(tape_ld + (int64_t)tl * ts + cg2 + (4 * H + jg + JS * i) * 32);
+    }
 
     for (int sb = 0; sb < T; ++sb) {
         const int step = T - 1 - sb;
         const int t = d == 0 ? step : T - 1 - step;
         const int tp = d == 0 ? t - 1 : t + 1;
-        f32x2 ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], dyv[UPT];
+        f32x2 ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], cpv[UPT], dyv[UPT];
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
-            ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cn[i] = n_cn[i]; dyv[i] = n_dy[i];
+            ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cn[i] = ccur[i]; cpv[i] = n_cp[i]; dyv[i] = n_dy[i];
+            ccur[i] = cpv[i];          // the state this step started from is the next processed step's own
         }
-        if (step > 0) fetch(tp);   // n_cn is then c of the previous step: the cell state this step started from
+        fetch(step > 0 ? tp : t);      // (the last processed step fetches itself again: unused)
 #pragma unroll
         for (int i = 0; i < UPT; ++i) {
             const int j = jg + JS * i;
@@ -295,7 +309,7 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
                     float dh = dhr[i][k];
                     if (dy) dh += dyv[i][k];
                     if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i][k];
-                    const float cp = (step > 0 && tp < len[k]) ? n_cn[i][k] : 0.0f;
+                    const float cp = (step > 0 && tp < len[k]) ? cpv[i][k] : 0.0f;
                     const float tc = snn_tanh(cn[i][k]);
                     const float dct = dc[i][k] + dh * og[i][k] * (1.0f - tc * tc);
                     dao[k] = dh * tc * og[i][k] * (1.0f - og[i][k]);
