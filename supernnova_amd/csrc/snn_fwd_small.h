@@ -74,9 +74,12 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         for (int u = 0; u < 4; ++u)
             mmid[u] = mask_mid(mk, c.s, y.L, p.n_curves, DIRS * H, l, 0, c.orig, d * H + j0 + u);
     }
-    // Staging is branch-free: a thread beyond the image duplicates its last float4 (same value to the same LDS address)
-    // and the step after the last re-stages the last one -- loads under `if (f < NF4)` / `if (more)` made the compiler
-    // put s_waitcnt vmcnt at the joins (snn_forward_big.hip has the measurement).
+    // Inference: staging is branch-free -- a thread beyond the image duplicates its last float4 (same value to the same
+    // LDS address) and the step after the last re-stages the last one; loads under `if (f < NF4)` / `if (more)` made the
+    // compiler put s_waitcnt vmcnt at the joins (snn_forward_big.hip has the measurement; GRU inference 55.7 -> 59.0 % of
+    // peak).  TRAIN keeps the guarded loads: with two workgroups per compute unit covering each other and the tape
+    // stores in flight, the same-box comparison read 1.41 ms (guarded) against 1.45 ms (branch-free) for the forward of
+    // 65 536 curves.
     int fi[NPT];
 #pragma unroll
     for (int i = 0; i < NPT; ++i) fi[i] = c.tid + i * NT < NF4 ? c.tid + i * NT : NF4 - 1;
@@ -115,6 +118,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = fi[i];
+            if (TRAIN && c.tid + i * NT >= NF4) continue;
             const float* src;
             if (FIRST) src = in0 + (int64_t)t * XIN_STRIDE + f * 4;
             else {
@@ -131,6 +135,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const int f = fi[i];
+            if (TRAIN && c.tid + i * NT >= NF4) continue;
             f32x4 v = pre[i];
             if (MASKED && (FIRST || TRAIN)) {
                 if (!FIRST && mid_step) {
@@ -175,13 +180,15 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
         f32x4 pre[NPT];
         const bool more = step + 1 < T;
         const int tn = more ? (d == 0 ? t + 1 : t - 1) : t;      // the step after the last: this one again (unused)
-        if (!GX) load_step(tn, pre);
+        if (!GX && (!TRAIN || more)) load_step(tn, pre);
 
         f32x16 acc;
         if (GX) {
             acc = gxn;
+            if (more) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];   // (after the last step: unused)
+                for (int i = 0; i < 16; ++i) gxn[i] = gxw[(int64_t)tn * NW * 1024 + i * 64];
+            }
             // tape row of the step before: staged in LDS by its cell update (below), written here as 16-byte words --
             // 6 store instructions per thread beside this step's MFMAs instead of 24 4-byte ones between the cell
             // update and the barrier (with one workgroup per compute unit nothing else hides their issue time)
@@ -277,7 +284,7 @@ __device__ __forceinline__ void run_phase(const FwdParams& p, const ItemCtx& c, 
             }
             }
         }
-        if (!GX) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
+        if (!GX && (!TRAIN || more)) store_step(xin + (cur ^ 1) * XIN_STRIDE, pre, tn);
         lds_barrier();
     }
     if (GX && TRAIN && T > 0) {      // the last step's tape row (its staging writes are behind the loop's closing barrier)
