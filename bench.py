@@ -544,9 +544,11 @@ def main():
         import bench_train
         torch.cuda.empty_cache()
 
-        def train_obj(per_rank, steps, warmup):
+        def train_obj(per_rank, steps, warmup, **over):
             a = bench_train.parser().parse_args([])
             a.gpus, a.batch, a.steps, a.warmup, a.cpu_steps = world, per_rank, steps, warmup, 0
+            for k, v in over.items():
+                setattr(a, k, v)
             r = bench_train.measure(a, rank, world, dev, backend)
             if r is None:
                 return None
@@ -562,6 +564,12 @@ def main():
 
         if world == 1 and default_run:
             tr = {"b128": train_obj(128, 200, 30), "b65536": train_obj(65536, 10, 3)}
+            # the wider models of BASELINE.json (configs[2]: H = 64; configs[4]: H = 128, D = 78, C = 14, 300-step curves)
+            # at chip-filling batches: split backward (snn_train_big.hip, snn_bwd_dx.hip), two-pass forward at H = 128
+            torch.cuda.empty_cache()
+            tr["h64_b65536"] = train_obj(65536, 6, 2, hidden=64)
+            torch.cuda.empty_cache()
+            tr["h128_t300_b8192"] = train_obj(8192, 4, 2, hidden=128, features=78, classes=14, max_len=300, full_length=True)
             out.setdefault("secondary", {})["train"] = tr
         elif world > 1:
             per = max(1, 128 // world)

@@ -202,9 +202,12 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
     constexpr int MB = H / 16;          // 16-unit blocks of dh
     constexpr int KSPLIT = NWV / MB;    // waves sharing one block (split over the gate rows)
     constexpr int KW = H / KSPLIT;      // k-steps (of 4 gate rows) per wave
-    constexpr int UPT = H * 8 / NTH;    // (hidden unit, 2 curves) items per thread in the element-wise stage
-    constexpr int JS = NTH / 8;         // unit stride of a thread's items
+    // element-wise stage: a thread owns W consecutive curves of hidden unit jg (one 8- or 16-byte word per tape row)
+    constexpr int W = H == 32 ? 2 : 4;
+    constexpr int TPR = 16 / W;         // threads per unit row of the half tile
+    static_assert(NTH / TPR == H, "one (unit, W curves) item per thread");
     static_assert(KSPLIT >= 1 && MB * KSPLIT == NWV, "one 16-unit block (or a K share of one) per wave");
+    typedef float fW __attribute__((ext_vector_type(W)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dGl = smem;                  // [4H][16] gate gradients of the running step (B operand image)
     float* red = dGl + 4 * H * 16;      // [KSPLIT][H][16]
@@ -217,13 +220,13 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
     const int T = p.tile_T[tile];
     const bool last_layer = l == y.L - 1;
-    const int c2 = (tid & 7) * 2, jg = tid >> 3;      // element-wise stage: 2 consecutive curves of units jg, jg + JS, ...
-    const int cg2 = 16 * half + c2;
-    int len[2];
-    float inv_len[2];
+    const int c0 = (tid % TPR) * W, j = tid / TPR;
+    const int cg = 16 * half + c0;
+    int len[W];
+    float inv_len[W];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        len[k] = p.len_sorted[tile * SNN_TILE + cg2 + k];
+    for (int k = 0; k < W; ++k) {
+        len[k] = p.len_sorted[tile * SNN_TILE + cg + k];
         inv_len[k] = 1.0f / (float)(len[k] > 0 ? len[k] : 1);
     }
     const int64_t ts = tape_step_floats(H);
@@ -236,124 +239,145 @@ __global__ void __launch_bounds__(H == 128 ? 512 : 256) bwd_rec16_kernel(const B
     const int mb = w / KSPLIT, ks = w - mb * KSPLIT;
     float wT[KW];
     {
-        const int j = 16 * mb + c;
-        const float* A = p.WT + p.wt_hh[ld] + (int64_t)(j >> 5) * 2 * H * 64 + (j & 31);
+        const int ju = 16 * mb + c;
+        const float* A = p.WT + p.wt_hh[ld] + (int64_t)(ju >> 5) * 2 * H * 64 + (ju & 31);
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) {
             const int R = ks * KW * 4 + 4 * kk + g;
             wT[kk] = A[(R >> 1) * 64 + (R & 1) * 32];
         }
     }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 zero2 = {0.f, 0.f};
-    f32x2 dc[UPT], dhr[UPT], dfm[UPT];
+    fW zeroW, dc, dhr, dfm;
 #pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-        const int j = jg + JS * i;
-        dc[i] = zero2;
-        dhr[i] = y.pool == SNN_POOL_STANDARD ? *reinterpret_cast<const f32x2*>(dfeat + (j * (y.L * dirs) + ld) * 32 + cg2) : zero2;
-        dfm[i] = zero2;
-        if (last_layer && y.pool == SNN_POOL_MEAN) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(dfeat + (d * H + j) * 32 + cg2);
-            dfm[i][0] = v[0] * inv_len[0];
-            dfm[i][1] = v[1] * inv_len[1];
-        }
+    for (int k = 0; k < W; ++k) zeroW[k] = 0.0f;
+    dc = zeroW;
+    dhr = y.pool == SNN_POOL_STANDARD ? *reinterpret_cast<const fW*>(dfeat + (j * (y.L * dirs) + ld) * 32 + cg) : zeroW;
+    dfm = zeroW;
+    if (last_layer && y.pool == SNN_POOL_MEAN) {
+        const fW v = *reinterpret_cast<const fW*>(dfeat + (d * H + j) * 32 + cg);
+#pragma unroll
+        for (int k = 0; k < W; ++k) dfm[k] = v[k] * inv_len[k];
     }
-    // Everything a step reads from the tape is fetched one step ahead by unconditional loads at clamped addresses (a
-    // load under `if (step > 0)` / `dy ? .. : ..` makes the compiler wait at the join): the gates and dy of step t, and
-    // the cell state its predecessor left (c_{t-1}: needed by the forget-gate gradient of step t).  A step's own c is
-    // the predecessor state fetched for the step processed before it, carried in a register -- fetched together with
-    // the other rows of step t - 1, it was awaited in the middle of step t, a trip to memory on the chain of every step.
-    f32x2 n_ig[UPT], n_fg[UPT], n_gg[UPT], n_og[UPT], n_cp[UPT], n_dy[UPT], ccur[UPT];
+    // Everything a step reads from the tape is fetched one step ahead by unconditional loads at clamped addresses: the
+    // gates and dy of step t, and the cell state its predecessor left (c_{t-1}: the forget-gate gradient of step t needs
+    // it).  A step's own c is the predecessor state fetched for the step processed before it, carried in a register.
+    // The 6 loads of that fetch and the 4 stores of this step's gate gradients are dealt out over the MFMAs of the step
+    // (vmem_piece): issued inside the element-wise stage, the 8 waves' memory instructions queued at the compute unit's
+    // one address unit -- clock64 probes read 3 700 cycles for that stage and as many at the barrier behind it, beside
+    // 8 200 cycles of MFMAs per SIMD and step (H = 128).
+    fW n_ig, n_fg, n_gg, n_og, n_cp, n_dy, ccur;
     const float* dyp = dy ? dy : tape_ld;      // (no dy: any readable address, the values are not used)
-    auto fetch = [&](int t) __attribute__((always_inline)) {
-        const float* tq = tape_ld + (int64_t)t * ts + cg2;
+    const float *tq_f = nullptr, *tc_f = nullptr, *dy_f = nullptr;
+    auto fetch_setup = [&](int t) __attribute__((always_inline)) {
         const int tpp = d == 0 ? (t > 0 ? t - 1 : 0) : (t + 1 < T ? t + 1 : T - 1);
-        const float* tc = tape_ld + (int64_t)tpp * ts + cg2;
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int j = jg + JS * i;
-            n_ig[i] = *reinterpret_cast<const f32x2*>(tq + (0 * H + j) * 32);
-            n_fg[i] = *reinterpret_cast<const f32x2*>(tq + (1 * H + j) * 32);
-            n_gg[i] = *reinterpret_cast<const f32x2*>(tq + (2 * H + j) * 32);
-            n_og[i] = *reinterpret_cast<const f32x2*>(tq + (3 * H + j) * 32);
-            n_cp[i] = *reinterpret_cast<const f32x2*>(tc + (4 * H + j) * 32);
-            n_dy[i] = *reinterpret_cast<const f32x2*>(dyp + (int64_t)t * H * 32 + j * 32 + cg2);
-        }
+        tq_f = tape_ld + (int64_t)t * ts + j * 32 + cg;
+        tc_f = tape_ld + (int64_t)tpp * ts + (4 * H + j) * 32 + cg;
+        dy_f = dyp + (int64_t)t * H * 32 + j * 32 + cg;
+    };
+    auto fetch_piece = [&](int q) __attribute__((always_inline)) {
+        if (q == 0) n_ig = *reinterpret_cast<const fW*>(tq_f + 0 * H * 32);
+        else if (q == 1) n_fg = *reinterpret_cast<const fW*>(tq_f + 1 * H * 32);
+        else if (q == 2) n_gg = *reinterpret_cast<const fW*>(tq_f + 2 * H * 32);
+        else if (q == 3) n_og = *reinterpret_cast<const fW*>(tq_f + 3 * H * 32);
+        else if (q == 4) n_cp = *reinterpret_cast<const fW*>(tc_f);
+        else n_dy = *reinterpret_cast<const fW*>(dy_f);
     };
     if (T > 0) {
         const int tl = d == 0 ? T - 1 : 0;
-        fetch(tl);
+        fetch_setup(tl);
 #pragma unroll
-        for (int i = 0; i < UPT; ++i) ccur[i] = *reinterpret_cast<const f32x2*>(tape_ld + (int64_t)tl * ts + cg2 + (4 * H + jg + JS * i) * 32);
+        for (int q = 0; q < 6; ++q) fetch_piece(q);
+        ccur = *reinterpret_cast<const fW*>(tape_ld + (int64_t)tl * ts + (4 * H + j) * 32 + cg);
     }
 
+#ifdef SNN_PROBE_REC16   // clock64 probes of workgroup 0, wave 0: cycles per step in each part of the loop
+    long long pc[6] = {0, 0, 0, 0, 0, 0};
+#define PROBE(i) { const long long now_ = clock64(); pc[i] += now_ - pt_; pt_ = now_; }
+#else
+#define PROBE(i)
+#endif
     for (int sb = 0; sb < T; ++sb) {
+#ifdef SNN_PROBE_REC16
+        long long pt_ = clock64();
+#endif
         const int step = T - 1 - sb;
         const int t = d == 0 ? step : T - 1 - step;
         const int tp = d == 0 ? t - 1 : t + 1;
-        f32x2 ig[UPT], fg[UPT], gg[UPT], og[UPT], cn[UPT], cpv[UPT], dyv[UPT];
+        const fW ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, cn = ccur, cpv = n_cp, dyv = n_dy;
+        ccur = cpv;                          // the state this step started from is the next processed step's own
+        fetch_setup(step > 0 ? tp : t);      // (the last processed step fetches itself again: unused)
+        fW dai = zeroW, daf = zeroW, dag = zeroW, dao = zeroW;
 #pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            ig[i] = n_ig[i]; fg[i] = n_fg[i]; gg[i] = n_gg[i]; og[i] = n_og[i]; cn[i] = ccur[i]; cpv[i] = n_cp[i]; dyv[i] = n_dy[i];
-            ccur[i] = cpv[i];          // the state this step started from is the next processed step's own
-        }
-        fetch(step > 0 ? tp : t);      // (the last processed step fetches itself again: unused)
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int j = jg + JS * i;
-            f32x2 dai = zero2, daf = zero2, dag = zero2, dao = zero2;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (t < len[k]) {
-                    float dh = dhr[i][k];
-                    if (dy) dh += dyv[i][k];
-                    if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[i][k];
-                    const float cp = (step > 0 && tp < len[k]) ? cpv[i][k] : 0.0f;
-                    const float tc = snn_tanh(cn[i][k]);
-                    const float dct = dc[i][k] + dh * og[i][k] * (1.0f - tc * tc);
-                    dao[k] = dh * tc * og[i][k] * (1.0f - og[i][k]);
-                    dai[k] = dct * gg[i][k] * ig[i][k] * (1.0f - ig[i][k]);
-                    daf[k] = dct * cp * fg[i][k] * (1.0f - fg[i][k]);
-                    dag[k] = dct * ig[i][k] * (1.0f - gg[i][k] * gg[i][k]);
-                    dc[i][k] = dct * fg[i][k];
-                }
+        for (int k = 0; k < W; ++k) {
+            if (t < len[k]) {
+                float dh = dhr[k];
+                if (dy) dh += dyv[k];
+                if (last_layer && y.pool == SNN_POOL_MEAN) dh += dfm[k];
+                const float cp = (step > 0 && tp < len[k]) ? cpv[k] : 0.0f;
+                const float tc = snn_tanh(cn[k]);
+                const float dct = dc[k] + dh * og[k] * (1.0f - tc * tc);
+                dao[k] = dh * tc * og[k] * (1.0f - og[k]);
+                dai[k] = dct * gg[k] * ig[k] * (1.0f - ig[k]);
+                daf[k] = dct * cp * fg[k] * (1.0f - fg[k]);
+                dag[k] = dct * ig[k] * (1.0f - gg[k] * gg[k]);
+                dc[k] = dct * fg[k];
             }
-            *reinterpret_cast<f32x2*>(dGl + (0 * H + j) * 16 + c2) = dai;
-            *reinterpret_cast<f32x2*>(dGl + (1 * H + j) * 16 + c2) = daf;
-            *reinterpret_cast<f32x2*>(dGl + (2 * H + j) * 16 + c2) = dag;
-            *reinterpret_cast<f32x2*>(dGl + (3 * H + j) * 16 + c2) = dao;
-            float* o = dGg + (int64_t)t * 4 * H * 32 + j * 32 + cg2;
-            *reinterpret_cast<f32x2*>(o + 0 * H * 32) = dai;
-            *reinterpret_cast<f32x2*>(o + 1 * H * 32) = daf;
-            *reinterpret_cast<f32x2*>(o + 2 * H * 32) = dag;
-            *reinterpret_cast<f32x2*>(o + 3 * H * 32) = dao;
         }
+        *reinterpret_cast<fW*>(dGl + (0 * H + j) * 16 + c0) = dai;
+        *reinterpret_cast<fW*>(dGl + (1 * H + j) * 16 + c0) = daf;
+        *reinterpret_cast<fW*>(dGl + (2 * H + j) * 16 + c0) = dag;
+        *reinterpret_cast<fW*>(dGl + (3 * H + j) * 16 + c0) = dao;
+        float* o = dGg + (int64_t)t * 4 * H * 32 + j * 32 + cg;
+        auto vmem_piece = [&](int q) __attribute__((always_inline)) {      // q < 6: next step's loads; then the 4 stores
+            if (q < 6) fetch_piece(q);
+            else if (q == 6) *reinterpret_cast<fW*>(o + 0 * H * 32) = dai;
+            else if (q == 7) *reinterpret_cast<fW*>(o + 1 * H * 32) = daf;
+            else if (q == 8) *reinterpret_cast<fW*>(o + 2 * H * 32) = dag;
+            else *reinterpret_cast<fW*>(o + 3 * H * 32) = dao;
+        };
+        PROBE(0)
         __syncthreads();
+        PROBE(1)
         {   // dh_{prev}[unit][curve] = sum_R W_hh[R][unit] dG[R][curve]: this wave's unit block mb, gate rows of split ks
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* bq = dGl + ks * KW * 64 + lane;      // row 4 kk + g, column c  ==  kk * 64 + lane
+            constexpr int NVP = 10, EVERY = KW / NVP > 0 ? KW / NVP : 1;
+            static_assert(KW >= NVP, "one memory instruction behind an MFMA at most");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < KW; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wT[kk], bq[kk * 64], acc, 0, 0, 0);
+            for (int kk = 0; kk < KW; ++kk) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wT[kk], bq[kk * 64], acc, 0, 0, 0);
+                if (kk % EVERY == 0 && kk / EVERY < NVP) {
+                    vmem_piece(kk / EVERY);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[(ks * H + 16 * mb + 4 * g + i) * 16 + c] = acc[i];
         }
+        PROBE(2)
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int j = jg + JS * i;
-            f32x2 s = zero2;
+        PROBE(3)
+        {
+            fW s = zeroW;
 #pragma unroll
             for (int k = 0; k < KSPLIT; ++k) {
-                const f32x2 rv = *reinterpret_cast<const f32x2*>(red + (k * H + j) * 16 + c2);
-                s[0] += rv[0];
-                s[1] += rv[1];
+                const fW rv = *reinterpret_cast<const fW*>(red + (k * H + j) * 16 + c0);
+#pragma unroll
+                for (int e = 0; e < W; ++e) s[e] += rv[e];
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e)      // beyond the curve the state is frozen: the gradient passes through unchanged
-                if (t < len[e]) dhr[i][e] = s[e];
+            for (int e = 0; e < W; ++e)      // beyond the curve the state is frozen: the gradient passes through unchanged
+                if (t < len[e]) dhr[e] = s[e];
         }
+        PROBE(4)
     }
+#ifdef SNN_PROBE_REC16
+    if (blockIdx.x == 0 && tid == 0 && T > 0)
+        printf("bwd_rec16<%d> %d steps: algebra %lld  barrier %lld  mfma %lld  barrier %lld  reduce %lld cycles per step\n", H, T,
+               pc[0] / T, pc[1] / T, pc[2] / T, pc[3] / T, pc[4] / T);
+#endif
+#undef PROBE
 }
 
 int snn_launch_bwd_rec16(const Bwd2Params& p, int l, hipStream_t st)
