@@ -509,11 +509,13 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 // ---- persistent forward launch geometry ------------------------------------
 struct FwdGeom { int grid, nbuf, cus, threads; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
-static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g, bool pair = false)
+static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g, bool pair = false, bool big_train = false)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
     const int threads = big ? 256 : y.H * 8;
-    if (big) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 3 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
+    // (lstm_fwd_big_kernel<TRAIN>: the x image is at least one tape row -- its staging buffer -- and there is no mask image)
+    if (big && big_train) g->lds = sizeof(float) * ((size_t)std::max(2 * rows * 32, SNN_TAPE_Q * y.H * 32) + 2 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
+    else if (big) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 3 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
     else if (pair) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)2 * (y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     else g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 2 * y.H * 32 + (size_t)(y.NW + 1) * y.C * 32 + y.NW * 32) + 16;
     if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
@@ -758,7 +760,7 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
         if (fp) { fn = fp; pair = true; }
     }
     FwdGeom g;
-    rc = fwd_geom(y, fn, e->big, max_T, &g, pair);
+    rc = fwd_geom(y, fn, e->big, max_T, &g, pair, e->big && train);
     if (rc) return rc;
     if (fit_grid && (rc = fit_grid_to_workspace(&g, 256, workspace_bytes, max_T))) return rc;
     if (workspace_bytes < g.ws_bytes) {

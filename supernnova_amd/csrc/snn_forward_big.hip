@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "snn_kernels.h"
 #include "snn_host.h"
@@ -220,75 +221,183 @@ pass2:
             hb[(8 * (c.w * RT + r) + 4 * c.hf + u) * 32 + c.cl] = 0.0f;
         }
     f32x16 acc[RT];
-    {
-        const int t0 = d == 0 ? 0 : T - 1;
+    const int t0 = d == 0 ? 0 : T - 1;
+    if constexpr (GX) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) load_gx(t0, r, acc[r]);
-    }
-    lds_barrier();
-    // The step body is ONE straight-line block: the "still inside the curve" selects are v_cndmask on a ballot (a C++
-    // select let the compiler sink each cell update under its own exec-mask branch: ~40 branches per step), the Gx of
-    // the step after the last is a (clamped, unused) reload of the last one, and the only branch left -- last layer or
-    // not -- is uniform and sits behind the activations.
-    for (int step = 0; step < T; ++step) {
-        const int t = d == 0 ? step : T - 1 - step;
-        const int tn = d == 0 ? (t + 1 < T ? t + 1 : t) : (t > 0 ? t - 1 : 0);
-        const int cur = step & 1;
-        const float* hc = hb + cur * (H * 32) + c.lane;
-#pragma unroll
-        for (int kk = 0; kk < KKH; ++kk) {
-            const float b = hc[kk * 64];
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
-        }
-        const unsigned long long vmask = __builtin_amdgcn_ballot_w64(t < c.len);
-        float outv[RT][4];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
-            float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float ig = snn_sigmoid(acc[r][u]);
-                const float fg = snn_sigmoid(acc[r][4 + u]);
-                const float gg = snn_tanh(acc[r][8 + u]);
-                const float og = snn_sigmoid(acc[r][12 + u]);
-                const float cn = fmaf(fg, cst[r][u], __fmul_rn(ig, gg));
-                const float hv = og * snn_tanh(cn);
-                cst[r][u] = lane_select(vmask, cn, cst[r][u]);
-                hst[r][u] = lane_select(vmask, hv, hst[r][u]);
-                outv[r][u] = lane_select(vmask, hv, 0.0f);
-                hn[u * 32] = hst[r][u];
-                if (TRAIN) {
-                    float* tp = tape_ld + (int64_t)t * tape_step_floats(H) + (j0 + u) * 32 + c.cl;
-                    tp[0 * H * 32] = ig;
-                    tp[1 * H * 32] = fg;
-                    tp[2 * H * 32] = gg;
-                    tp[3 * H * 32] = og;
-                    tp[4 * H * 32] = cn;
-                    tp[5 * H * 32] = outv[r][u];
+        lds_barrier();
+        // The step body is ONE straight-line block: the "still inside the curve" selects are v_cndmask on a ballot (a C++
+        // select let the compiler sink each cell update under its own exec-mask branch: ~40 branches per step), the Gx of
+        // the step after the last is a (clamped, unused) reload of the last one, and the only branch left -- last layer or
+        // not -- is uniform and sits behind the activations.
+        for (int step = 0; step < T; ++step) {
+            const int t = d == 0 ? step : T - 1 - step;
+            const int tn = d == 0 ? (t + 1 < T ? t + 1 : t) : (t > 0 ? t - 1 : 0);
+            const int cur = step & 1;
+            const float* hc = hb + cur * (H * 32) + c.lane;
+    #pragma unroll
+            for (int kk = 0; kk < KKH; ++kk) {
+                const float b = hc[kk * 64];
+    #pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
+            }
+            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(t < c.len);
+            float outv[RT][4];
+    #pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
+                float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ig = snn_sigmoid(acc[r][u]);
+                    const float fg = snn_sigmoid(acc[r][4 + u]);
+                    const float gg = snn_tanh(acc[r][8 + u]);
+                    const float og = snn_sigmoid(acc[r][12 + u]);
+                    const float cn = fmaf(fg, cst[r][u], __fmul_rn(ig, gg));
+                    const float hv = og * snn_tanh(cn);
+                    cst[r][u] = lane_select(vmask, cn, cst[r][u]);
+                    hst[r][u] = lane_select(vmask, hv, hst[r][u]);
+                    outv[r][u] = lane_select(vmask, hv, 0.0f);
+                    hn[u * 32] = hst[r][u];
+                    if (TRAIN) {
+                        float* tp = tape_ld + (int64_t)t * tape_step_floats(H) + (j0 + u) * 32 + c.cl;
+                        tp[0 * H * 32] = ig;
+                        tp[1 * H * 32] = fg;
+                        tp[2 * H * 32] = gg;
+                        tp[3 * H * 32] = og;
+                        tp[4 * H * 32] = cn;
+                        tp[5 * H * 32] = outv[r][u];
+                    }
+                }
+                // the next step's Gx for this tile goes straight into the now-free accumulator
+    #ifndef SNN_ABL_BIG_NOGX   // (timing ablation only, results are wrong: no Gx reload)
+                load_gx(tn, r, acc[r]);
+    #endif
+            }
+            if (last_layer) {
+    #pragma unroll
+                for (int r = 0; r < RT; ++r)
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) hsum[r][u] += outv[r][u];
+            } else if (!TRAIN) {
+    #pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
+                    float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) yo[u * 32] = MASKED ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[r][u]) : outv[r][u];
                 }
             }
-            // the next step's Gx for this tile goes straight into the now-free accumulator
-#ifndef SNN_ABL_BIG_NOGX   // (timing ablation only, results are wrong: no Gx reload)
-            load_gx(tn, r, acc[r]);
-#endif
+            lds_barrier();
         }
-        if (last_layer) {
+    } else {
+    // Large batches (one workgroup per compute unit, nothing else to run under a wave's memory instructions): what a step
+    // stores is dealt out over the 64 k-steps of the NEXT step's MFMA block:
+    // the layer outputs (inference) or the tape row (training), which the cell update parks in registers / in LDS
+    // (`stage`: the x image of the input pass is free by now; rows are wave-private, so no barrier guards them) and which
+    // leave as 16-byte words.  Issued inside the cell update, the 4 waves' 96 four-byte tape stores per lane (or 16 y
+    // stores + 16 Gx loads) queued at the compute unit's one address unit behind the MFMAs: the recurrent pass ran at
+    // 55 % (training) / 70 % (inference) of its MFMA time.
+    constexpr bool STG = TRAIN;
+    float* stage = xin;                                   // [6][H*32] tape row of the step before (TRAIN)
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
+    for (int r = 0; r < RT; ++r) load_gx(t0, r, acc[r]);
+    lds_barrier();
+    const int lane_row = (32 * c.w + (c.lane >> 3)) * 32 + (c.lane & 7) * 4;   // flush: this lane's 16-byte word of piece 0
+    auto steps = [&](auto ysf) __attribute__((always_inline)) {
+        constexpr bool YS = decltype(ysf)::value;         // inference, not the last layer: layer outputs are stored
+        float yprev[RT][4];
+        auto one_step = [&](auto flf, int step) __attribute__((always_inline)) {
+            constexpr bool FL = decltype(flf)::value;     // a step before this one exists: its stores go out beside these MFMAs
+            const int t = d == 0 ? step : T - 1 - step;
+            const int tn = d == 0 ? (t + 1 < T ? t + 1 : t) : (t > 0 ? t - 1 : 0);
+            const int tprev = d == 0 ? t - 1 : t + 1;
+            const int cur = step & 1;
+            const float* hc = hb + cur * (H * 32) + c.lane;
+            constexpr int BA = 4;
+            float bq[BA];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) hsum[r][u] += outv[r][u];
-        } else if (!TRAIN) {
+            for (int kk = 0; kk < BA; ++kk) bq[kk] = hc[kk * 64];
+            f32x4 fv = {0.f, 0.f, 0.f, 0.f};
+            float* trow = TRAIN ? tape_ld + (int64_t)tprev * tape_step_floats(H) + lane_row : nullptr;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KKH; ++kk) {
+                const float b = bq[kk % BA];
+                if (kk + BA < KKH) bq[kk % BA] = hc[(kk + BA) * 64];
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
+                if (FL && YS && kk >= 24 && kk < 24 + 4 * RT) {   // layer outputs of the step before
+                    const int r = (kk - 24) >> 2, u = (kk - 24) & 3;
+                    yout[(int64_t)tprev * (H * 32) + (8 * (c.w * RT + r) + 4 * c.hf + u) * 32 + c.cl] = yprev[r][u];
+                }
+                if (FL && STG && kk >= 16) {                // tape row of the step before: LDS -> 16-byte store, 24 words per lane
+                    const int pc = (kk - 16) >> 1, off = ((pc >> 2) * H + 8 * (pc & 3)) * 32;
+                    if (((kk - 16) & 1) == 0) fv = *reinterpret_cast<const f32x4*>(stage + lane_row + off);
+                    else *reinterpret_cast<f32x4*>(trow + off) = fv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(t < c.len);
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const int j0 = 8 * (c.w * RT + r) + 4 * c.hf;
-                float* yo = yout + (int64_t)t * (H * 32) + j0 * 32 + c.cl;
+                float* hn = hb + (cur ^ 1) * (H * 32) + j0 * 32 + c.cl;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) yo[u * 32] = MASKED ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv[r][u]) : outv[r][u];
+                for (int u = 0; u < 4; ++u) {
+                    const float ig = snn_sigmoid(acc[r][u]);
+                    const float fg = snn_sigmoid(acc[r][4 + u]);
+                    const float gg = snn_tanh(acc[r][8 + u]);
+                    const float og = snn_sigmoid(acc[r][12 + u]);
+                    const float cn = fmaf(fg, cst[r][u], __fmul_rn(ig, gg));
+                    const float hv = og * snn_tanh(cn);
+                    cst[r][u] = lane_select(vmask, cn, cst[r][u]);
+                    hst[r][u] = lane_select(vmask, hv, hst[r][u]);
+                    const float outv = lane_select(vmask, hv, 0.0f);
+                    hn[u * 32] = hst[r][u];
+                    if (TRAIN) {
+                        float* sg = stage + (j0 + u) * 32 + c.cl;
+                        sg[0 * H * 32] = ig;
+                        sg[1 * H * 32] = fg;
+                        sg[2 * H * 32] = gg;
+                        sg[3 * H * 32] = og;
+                        sg[4 * H * 32] = cn;
+                        sg[5 * H * 32] = outv;
+                    }
+                    if (!YS && last_layer) hsum[r][u] += outv;
+                    if (YS) yprev[r][u] = MASKED ? __fmul_rn(mlds[(j0 + u) * 32 + c.cl], outv) : outv;
+                }
+                // the next step's Gx for this tile goes straight into the now-free accumulator (a second register set
+                // for it, filled beside the MFMAs, spilled: 1 262 against 1 208 ms on the elasticc workload)
+#ifndef SNN_ABL_BIG_NOGX   // (timing ablation only, results are wrong: no Gx reload)
+                load_gx(tn, r, acc[r]);
+#endif
+            }
+            lds_barrier();
+        };
+        one_step(std::false_type{}, 0);
+        for (int step = 1; step < T; ++step) one_step(std::true_type{}, step);
+        // the last step's stores
+        const int tl = d == 0 ? T - 1 : 0;
+        if (YS) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    yout[(int64_t)tl * (H * 32) + (8 * (c.w * RT + r) + 4 * c.hf + u) * 32 + c.cl] = yprev[r][u];
+        }
+        if (STG) {
+            float* trow = tape_ld + (int64_t)tl * tape_step_floats(H) + lane_row;
+#pragma unroll
+            for (int pc = 0; pc < 24; ++pc) {
+                const int off = ((pc >> 2) * H + 8 * (pc & 3)) * 32;
+                *reinterpret_cast<f32x4*>(trow + off) = *reinterpret_cast<const f32x4*>(stage + lane_row + off);
             }
         }
-        lds_barrier();
+    };
+    if (!TRAIN && !last_layer) steps(std::true_type{});
+    else steps(std::false_type{});
     }
 
     // ---- head contribution of this phase
@@ -342,10 +451,12 @@ __global__ void __launch_bounds__(256, 1) lstm_fwd_big_kernel(const FwdParams p)
     constexpr int BLK0 = NWT * (KKI0 + H / 2) * 64 + 2 * NWT * 32;
     constexpr int BLK1 = NWT * (KKI1 + H / 2) * 64 + 2 * NWT * 32;
     const int k_head_w = DIRS * BLK0 + (y.L - 1) * DIRS * BLK1;
-    float* xin = smem;                     // [2][ROWS*32]
-    float* hb = xin + 2 * ROWS * 32;       // [2][H*32]
-    float* mlds = hb + 2 * H * 32;         // [H*32]
-    float* part = mlds + H * 32;           // [4][C][32]
+    // TRAIN: the x image doubles as the staging row of the tape in the recurrent pass (6 x H x 32 floats); no mask image
+    constexpr int XIN = TRAIN ? (2 * ROWS * 32 > SNN_TAPE_Q * H * 32 ? 2 * ROWS * 32 : SNN_TAPE_Q * H * 32) : 2 * ROWS * 32;
+    float* xin = smem;                     // [2][ROWS*32] (TRAIN: at least [6][H*32])
+    float* hb = xin + XIN;                 // [2][H*32]
+    float* mlds = hb + 2 * H * 32;         // [H*32] (inference only)
+    float* part = mlds + (TRAIN ? 0 : H * 32);   // [4][C][32]
     float* logit = part + 4 * y.C * 32;    // [C][32]
     int* item_slot = reinterpret_cast<int*>(logit + y.C * 32);
 
