@@ -19,6 +19,9 @@
 #include "snn_kernels.h"
 #include "snn_host.h"
 
+#ifndef SNN_BIG_AG
+#define SNN_BIG_AG 2     // row tiles (of 4 per wave) whose W_hh stays in VGPRs in the recurrent pass; the others are read from AGPRs
+#endif
 // One (layer, direction) phase.  TP = row tiles per wave handled by one input pass.
 // GX: pass 1 was done by fwd_gx_kernel (snn_fwd_gx.hip) for all tiles at once; `gx` is this (tile, direction)'s block.
 // MASKED = false is launched for models without dropout masks only: no Philox code in the kernel at all.
@@ -300,6 +303,9 @@ pass2:
     // 55 % (training) / 70 % (inference) of its MFMA time.
     constexpr bool STG = TRAIN;
     float* stage = xin;                                   // [6][H*32] tape row of the step before (TRAIN)
+#ifdef SNN_PROBE_BIG   // clock64 probes, wave 0 of workgroup 0: cycles per step of the recurrent pass (MFMA block | cell | barrier)
+    long long pcyc[3] = {0, 0, 0};
+#endif
 #pragma unroll
     for (int r = 0; r < RT; ++r) load_gx(t0, r, acc[r]);
     lds_barrier();
@@ -314,6 +320,12 @@ pass2:
             const int tprev = d == 0 ? t - 1 : t + 1;
             const int cur = step & 1;
             const float* hc = hb + cur * (H * 32) + c.lane;
+#ifdef SNN_PROBE_BIG
+            long long pt_ = clock64();
+#define PROBE(i) { const long long now_ = clock64(); pcyc[i] += now_ - pt_; pt_ = now_; }
+#else
+#define PROBE(i)
+#endif
             constexpr int BA = 4;
             float bq[BA];
 #pragma unroll
@@ -325,9 +337,18 @@ pass2:
             for (int kk = 0; kk < KKH; ++kk) {
                 const float b = bq[kk % BA];
                 if (kk + BA < KKH) bq[kk % BA] = hc[(kk + BA) * 64];
+                // W_hh is 256 registers per lane: with the accumulators and the cell state beside it, the compiler parks part
+                // of it in AGPRs and copies each value to a VGPR in front of its MFMA (~150 v_accvgpr_read + hazard nops per
+                // step, on the pipe the MFMAs need: clock64 probes read 20 000 cycles for the 256 MFMAs of a step).  The
+                // matrix instruction can read its A operand from an AGPR directly; the compiler does not select that form, so
+                // the upper half of the row tiles issues it as inline asm with the weight constrained to an AGPR.
 #pragma unroll
-                for (int r = 0; r < RT; ++r)
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
+                for (int r = 0; r < RT; ++r) {
+                    if (!TRAIN && r >= SNN_BIG_AG)      // (training: the tape staging changes the allocation, and the form costs there: 28.2 -> 32.8 ms)
+                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[r]) : "a"(wh[r][kk]), "v"(b));
+                    else
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
+                }
                 if (FL && YS && kk >= 24 && kk < 24 + 4 * RT) {   // layer outputs of the step before
                     const int r = (kk - 24) >> 2, u = (kk - 24) & 3;
                     yout[(int64_t)tprev * (H * 32) + (8 * (c.w * RT + r) + 4 * c.hf + u) * 32 + c.cl] = yprev[r][u];
@@ -339,6 +360,10 @@ pass2:
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (the compiler does not know the asm statements are matrix instructions: the wait states it would put between
+            // a 16-pass MFMA and the first vector read of its result are given here)
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            PROBE(0)
             const unsigned long long vmask = __builtin_amdgcn_ballot_w64(t < c.len);
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
@@ -374,7 +399,10 @@ pass2:
                 load_gx(tn, r, acc[r]);
 #endif
             }
+            PROBE(1)
             lds_barrier();
+            PROBE(2)
+#undef PROBE
         };
         one_step(std::false_type{}, 0);
         for (int step = 1; step < T; ++step) one_step(std::true_type{}, step);
@@ -398,6 +426,10 @@ pass2:
     };
     if (!TRAIN && !last_layer) steps(std::true_type{});
     else steps(std::false_type{});
+#ifdef SNN_PROBE_BIG
+    if (blockIdx.x == 0 && c.tid == 0 && c.s == 0)
+        printf("big pass 2 (l %d d %d, %d steps): mfma %lld  cell %lld  barrier %lld cycles per step\n", l, d, T, pcyc[0] / T, pcyc[1] / T, pcyc[2] / T);
+#endif
     }
 
     // ---- head contribution of this phase
