@@ -324,6 +324,7 @@ const FwdSmallEntry* snn_fwd_small_h32(int KKI0, int dirs);   // snn_fwd_h32.hip
 const FwdSmallEntry* snn_fwd_small_h64(int KKI0, int dirs);   // snn_fwd_h64.hip
 fwd_kernel_t snn_big_kernel(int H, int KKI0, int dirs, bool train, bool masked);  // snn_forward_big.hip
 fwd_kernel_t snn_pair_kernel(int H, int KKI0, int dirs, bool masked);      // snn_forward_pair.hip
+fwd_kernel_t snn_wpt_kernel(int H, int KKI0, int dirs, int cell);          // snn_forward_wpt.hip (GRU / tanh RNN, one wave per tile)
 typedef void (*fwd_b3_kernel_t)(const FwdParams, const B3Offsets);
 fwd_b3_kernel_t snn_b3_kernel(int H, int XB0, int dirs);      // snn_forward_b3.hip (SNN_PREC_BF16X3)
 fwd_b3_kernel_t snn_b3p_kernel(int H, int XB0, int dirs);     // snn_forward_b3p.hip (same, two tiles per workgroup)
@@ -509,10 +510,26 @@ extern "C" int snn_bbb_sample(const snn_cfg* cfg, const float* mu, const float* 
 // ---- persistent forward launch geometry ------------------------------------
 struct FwdGeom { int grid, nbuf, cus, threads; size_t lds; int64_t y_buf_floats; int64_t ws_bytes; };
 
-static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g, bool pair = false, bool big_train = false)
+static int fwd_geom(const SnnLayout& y, fwd_kernel_t fn, bool big, int max_T, FwdGeom* g, bool pair = false, bool big_train = false,
+                    bool wpt = false)
 {
     const int rows = std::max(2 * y.KKI[0], y.dirs * y.H);
     const int threads = big ? 256 : y.H * 8;
+    if (wpt) {   // wpt_fwd_kernel: four waves, a tile each -- wave-private h images and logits, four y slabs per workgroup
+        g->lds = sizeof(float) * ((size_t)4 * y.H * 32 + 4 * 128 + (size_t)4 * y.C * 32) + 16;
+        if (g->lds > 160 * 1024) { snn_set_error("LDS request %zu exceeds 160 KiB (nb_classes too large)", g->lds); return SNN_ERR_UNSUPPORTED; }
+        int dev = 0, cus = 0, per_cu = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g->lds));
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)fn, 256, g->lds));
+        per_cu = std::max(1, std::min(8, per_cu));
+        g->grid = cus * per_cu; g->cus = cus; g->threads = 256;
+        g->nbuf = y.L > 2 ? 2 : 1;
+        g->y_buf_floats = (int64_t)y.dirs * max_T * y.H * 32;
+        g->ws_bytes = 256 + (int64_t)sizeof(float) * g->grid * 4 * g->nbuf * g->y_buf_floats;
+        return SNN_OK;
+    }
     // (lstm_fwd_big_kernel<TRAIN>: the x image is at least one tape row -- its staging buffer -- and there is no mask image)
     if (big && big_train) g->lds = sizeof(float) * ((size_t)std::max(2 * rows * 32, SNN_TAPE_Q * y.H * 32) + 2 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
     else if (big) g->lds = sizeof(float) * ((size_t)2 * rows * 32 + 3 * y.H * 32 + (size_t)5 * y.C * 32) + 16;
@@ -670,6 +687,10 @@ extern "C" int64_t snn_lstm_forward_workspace_bytes(const snn_cfg* cfg, int32_t 
     if (!rc && !e->big && y.cell != 0) {
         rc = fwd_geom(y, e->fn_train, false, max_T, &gt);
         if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+        if (fwd_kernel_t fw = rc ? nullptr : snn_wpt_kernel(y.H, y.KKI[0], y.dirs, y.cell)) {
+            rc = fwd_geom(y, fw, false, max_T, &gt, false, false, true);
+            if (!rc) g.ws_bytes = std::max(g.ws_bytes, gt.ws_bytes);
+        }
     }
     if (!rc && !e->big && y.cell == 0) {
         rc = fwd_geom(y, e->fn_masked, false, max_T, &gt);
@@ -759,8 +780,13 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
         fwd_kernel_t fp = no_pair ? nullptr : snn_pair_kernel(y.H, y.KKI[0], y.dirs, masked);
         if (fp) { fn = fp; pair = true; }
     }
+    // GRU / tanh RNN inference at H = 32: one wave per tile (snn_forward_wpt.hip); SNN_NO_WPT: the LSTM-shaped kernel (A/B, tests)
+    bool wpt = false;
+    if (!train && !masked && y.cell != 0 && !getenv("SNN_NO_WPT")) {
+        if (fwd_kernel_t fw = snn_wpt_kernel(y.H, y.KKI[0], y.dirs, y.cell)) { fn = fw; wpt = true; }
+    }
     FwdGeom g;
-    rc = fwd_geom(y, fn, e->big, max_T, &g, pair, e->big && train);
+    rc = fwd_geom(y, fn, e->big, max_T, &g, pair, e->big && train, wpt);
     if (rc) return rc;
     if (fit_grid && (rc = fit_grid_to_workspace(&g, 256, workspace_bytes, max_T))) return rc;
     if (workspace_bytes < g.ws_bytes) {
@@ -837,10 +863,10 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     }
     // (n_part / rec16 above concern the split path only: the layer-wise kernel exists for H = 32 / 64, where n_part is NW)
     HIP_CHECK(hipMemsetAsync(workspace, 0, 256, st));
-    const int64_t n_items = (int64_t)(pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
+    const int64_t n_items = (int64_t)(wpt ? (n_tiles + 3) / 4 : pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d,%d,%s> grid=%d block=%d lds=%zu",
-             pair ? "lstm_fwd_pair_kernel" : e->big ? "lstm_fwd_big_kernel" : "lstm_fwd_kernel", y.H, y.KKI[0], y.dirs,
+             wpt ? (y.cell == 1 ? "wpt_fwd_kernel(gru)" : "wpt_fwd_kernel(rnn)") : pair ? "lstm_fwd_pair_kernel" : e->big ? "lstm_fwd_big_kernel" : "lstm_fwd_kernel", y.H, y.KKI[0], y.dirs,
              train ? "train" : masked ? "masked" : "plain", grid, g.threads, g.lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds, st, p);
     HIP_CHECK(hipGetLastError());
