@@ -866,8 +866,8 @@ static int launch_forward(const snn_cfg* cfg, bool train, const float* xp, const
     const int64_t n_items = (int64_t)(wpt ? (n_tiles + 3) / 4 : pair ? (n_tiles + 1) / 2 : n_tiles) * n_samples;
     const int grid = (int)std::min<int64_t>(g.grid, n_items);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d,%d,%d,%s> grid=%d block=%d lds=%zu",
-             wpt ? (y.cell == 1 ? "wpt_fwd_kernel(gru)" : "wpt_fwd_kernel(rnn)") : pair ? "lstm_fwd_pair_kernel" : e->big ? "lstm_fwd_big_kernel" : "lstm_fwd_kernel", y.H, y.KKI[0], y.dirs,
-             train ? "train" : masked ? "masked" : "plain", grid, g.threads, g.lds);
+             wpt ? "wpt_fwd_kernel" : pair ? "lstm_fwd_pair_kernel" : e->big ? "lstm_fwd_big_kernel" : "lstm_fwd_kernel", y.H, y.KKI[0], y.dirs,
+             train ? "train" : masked ? "masked" : wpt ? (y.cell == 1 ? "gru" : "rnn") : "plain", grid, g.threads, g.lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds, st, p);
     HIP_CHECK(hipGetLastError());
     return SNN_OK;
