@@ -432,6 +432,37 @@ def test_gru_rnn_vs_oracle_ragged(cell, D, H, L, bidir, C, pool):
         _check(lo[s], pr[s], o["logits"], o["probs"])
 
 
+@pytest.mark.parametrize("cell", ["gru", "rnn"])
+@pytest.mark.parametrize("D,L,bidir,C,pool,N,T", [(24, 2, True, 2, "mean", 1000, 40), (78, 3, True, 5, "standard", 131, 23),
+                                                  (26, 1, False, 3, "mean", 33, 7)])
+def test_wave_per_tile_kernel_matches_the_lstm_shaped_one(cell, D, L, bidir, C, pool, N, T):
+    """Un-masked GRU / tanh-RNN inference at H = 32 runs wpt_fwd_kernel (snn_forward_wpt.hip: one wave per tile, unit-major
+    row tiles, no workgroup barrier); SNN_NO_WPT=1 selects lstm_fwd_kernel<.., CELL>.  Same products in the same order per
+    gate pre-activation; the head sums 16 units per lane instead of 4: logits within LOGIT_ATOL, several weight sets,
+    tile groups with missing tiles (N / 32 not a multiple of 4), three layers (two y buffers)."""
+    import os
+    E = _eng()
+    S = 2
+    cfg = E.Config(D, 32, L, bidir, C, pool, cell=cell)
+    g = np.random.default_rng(21)
+    ws = g.uniform(-0.2, 0.2, (S, cfg.P)).astype(np.float32)
+    x, lengths = make_curves(13, N, T, D, min_len=1)
+    wk = E.prepare_weights_multi(cfg, _t(ws))
+    res = {}
+    for v in (None, "1"):
+        if v:
+            os.environ["SNN_NO_WPT"] = v
+        try:
+            lo, pr = _run(E, cfg, x, lengths, wk, S)
+            name = E.last_forward_kernel()
+        finally:
+            os.environ.pop("SNN_NO_WPT", None)
+        assert ("wpt_fwd_kernel" in name) == (v is None), name
+        res[v] = (lo, pr)
+    for s in range(S):
+        _check(res[None][0][s], res[None][1][s], res["1"][0][s], res["1"][1][s])
+
+
 def test_gru_rnn_cells_refuse_what_they_do_not_implement():
     """GRU / tanh-RNN cells run inference and training (tests/test_gpu_train.py), but have no Bayes-by-Backprop path
     (bayesian_rnn.py:47-69 registers the LSTM only), no split-precision kernel and no masked *inference* kernel: those
