@@ -74,12 +74,20 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
         for (int g = 0; g < NG; ++g) bl[(g * 2 + c.hf) * 16 + c.cl] = gather_bias(c.wks, k_bias, g, c.hf, c.cl);
     }
 
-    // ---- B operands of the input k-steps: x_t rows / the layer below's outputs, as they lie in memory
+    // ---- B operands of the input k-steps: x_t rows / the layer below's outputs, as they lie in memory.  One base address
+    // per step (and per direction of the layer below); the k-steps are immediate offsets of it.
     const float* in0 = FIRST ? p.xp + p.tile_off[c.tile] : c.ybase + (int64_t)((l - 1) % p.nbuf) * p.y_buf_floats;
-    auto xsrc = [&](int t, int kk) -> const float* {
-        if (FIRST) return in0 + (int64_t)t * (2 * KKI * 32) + kk * 64 + c.lane;
-        const int dd = kk / KKH, kr = kk - dd * KKH;                                   // (KKI = DIRS * 16)
-        return in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + kr * 64 + c.lane;
+    constexpr int NXB = FIRST ? 1 : DIRS;           // base pointers per step
+    auto xbase = [&](int t, const float* (&xb)[NXB]) __attribute__((always_inline)) {
+        if (FIRST) xb[0] = in0 + (int64_t)t * (2 * KKI * 32) + c.lane;
+        else {
+#pragma unroll
+            for (int dd = 0; dd < NXB; ++dd) xb[dd] = in0 + ((int64_t)dd * p.max_T + t) * (H * 32) + c.lane;
+        }
+    };
+    auto xload = [&](const float* const (&xb)[NXB], int kk) __attribute__((always_inline)) -> float {
+        if (FIRST) return xb[0][kk * 64];
+        return xb[kk / KKH][(kk % KKH) * 64];         // (KKI = DIRS * 16: k-step kk is row pair kk % 16 of direction kk / 16)
     };
     float* yout = last_layer ? nullptr : c.ybase + (int64_t)(l % p.nbuf) * p.y_buf_floats + (int64_t)d * p.max_T * (H * 32);
 
@@ -91,9 +99,10 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
     }
     float bx[KKI];
     {
-        const int t0 = d == 0 ? 0 : T - 1;
+        const float* xb[NXB];
+        xbase(d == 0 ? 0 : T - 1, xb);
 #pragma unroll
-        for (int kk = 0; kk < KKI; ++kk) bx[kk] = *xsrc(t0, kk);
+        for (int kk = 0; kk < KKI; ++kk) bx[kk] = xload(xb, kk);
     }
     for (int step = 0; step < T; ++step) {
         const int t = d == 0 ? step : T - 1 - step;
@@ -103,12 +112,20 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
         for (int g = 0; g < NG; ++g) acc[g] = *reinterpret_cast<const f32x16*>(bl + (g * 2 + c.hf) * 16);
         // input k-steps (independent of h: they run while the h image of the step before settles); each operand register
         // is refilled for the next step as soon as its MFMAs are issued
+        const float* xbn[NXB];
+        xbase(tn, xbn);
+        // GRU: the weights (144 registers in layer 1), four accumulators and the operand registers do not fit 256 VGPRs; the
+        // compiler then parks weights in AGPRs and copies each one to a VGPR in front of its MFMA.  The z chain and n's hidden
+        // half read their weights from AGPRs directly (inline asm, as in snn_forward_big.hip).
 #pragma unroll
         for (int kk = 0; kk < KKI; ++kk) {
             const float b = bx[kk];
-#pragma unroll
-            for (int q = 0; q < (CELL == 1 ? 3 : 1); ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[q][kk], b, acc[q], 0, 0, 0);
-            bx[kk] = *xsrc(tn, kk);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[0][kk], b, acc[0], 0, 0, 0);
+            if (CELL == 1) {
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[1]) : "a"(wx[1][kk]), "v"(b));
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[2][kk], b, acc[2], 0, 0, 0);
+            }
+            bx[kk] = xload(xbn, kk);
         }
         // recurrent k-steps: h_{t-1} from the wave's own LDS image, rows 2kk, 2kk+1 = 64 contiguous floats
 #pragma unroll
@@ -116,10 +133,11 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
             const float b = hl[kk * 64 + c.lane];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[0][kk], b, acc[0], 0, 0, 0);
             if (CELL == 1) {
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[1][kk], b, acc[1], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[2][kk], b, acc[3], 0, 0, 0);
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[1]) : "a"(wh[1][kk]), "v"(b));
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[3]) : "a"(wh[2][kk]), "v"(b));
             }
         }
+        if (CELL == 1) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (wait states between a 16-pass MFMA and a vector read of its result)
         const bool valid = t < c.len;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
