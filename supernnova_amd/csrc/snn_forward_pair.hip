@@ -167,33 +167,44 @@ __device__ __forceinline__ void pair_phase(const FwdParams& p, const PairCtx& c,
 #pragma unroll
         for (int u = 0; u < 4; ++u) cst[q][u] = hst[q][u] = hsum[q][u] = 0.0f;
 
-    // The cell update of one tile-step, cut into NPIECE pieces of 4-8 VALU instructions (<= ~36 cycles of vector
-    // issue each: they fit behind one 64-cycle MFMA).  Piece (u, st) works on hidden unit j0 + u.
-    constexpr int NPIECE = 24;
+    // The cell update of one tile-step, cut into NPIECE pieces placed behind the MFMAs of the other tile's chain.  A piece
+    // works on TWO hidden units (j0 + 2 up, j0 + 2 up + 1) at the same stage: each unit's stage is a dependent chain
+    // (v_exp -> v_add -> v_rcp -> v_fma), and a transcendental's consumer right behind it waits out its latency (the
+    // compiler also has to put an s_nop between them); with two independent chains in one scheduling region the
+    // instructions interleave and neither wait is paid.  SNN_PAIR_UNITS_PER_PIECE=1: one unit per piece (24 pieces).
+#ifndef SNN_PAIR_UNITS_PER_PIECE
+#define SNN_PAIR_UNITS_PER_PIECE 2
+#endif
+    constexpr int UPP = SNN_PAIR_UNITS_PER_PIECE;
+    constexpr int NPIECE = 24 / UPP;
     static_assert(KK >= NPIECE, "one cell-update piece per MFMA at most");
     struct ActRegs { float ig[4], fg[4], gg[4], og[4], tc[4]; };
     auto act_piece = [&](int q, int t, const f32x16& acc, ActRegs& r, unsigned long long vmask, int piece) {
-        const int u = piece / 6, st = piece % 6;
+        const int up = piece / 6, st = piece % 6;
         // `pin`: an empty volatile asm on the piece's input.  Volatile asms and sched_barrier keep their program
         // order, so the piece cannot be hoisted to the head of the chain (which the compiler otherwise does with
         // everything that only depends on the previous chain's accumulator).
         auto pin = [](float v) { asm volatile("" : "+v"(v)); return v; };
         // acc holds the exp2 exponents (scaled rows); gg and the cell state are carried times K2 = 2 log2 e
-        if (st == 0) r.ig[u] = sigmoid_exp2(pin(acc[u]));
-        else if (st == 1) r.gg[u] = fmaf(-2.0f * K2, rcp_1p_exp2(pin(acc[8 + u])), K2);                   // K2 * tanh(a_g)
-        else if (st == 2) r.fg[u] = sigmoid_exp2(pin(acc[4 + u]));
-        else if (st == 3) {
-            const float cn = fmaf(pin(r.fg[u]), cst[q][u], __fmul_rn(r.ig[u], r.gg[u]));                    // K2 * c_t
-            r.tc[u] = fmaf(-2.0f, rcp_1p_exp2(cn), 1.0f);                                                   // tanh(c_t)
-            cst[q][u] = UNIFORM ? cn : lane_select(vmask, cn, cst[q][u]);
-        } else if (st == 4) r.og[u] = sigmoid_exp2(pin(acc[12 + u]));
-        else {
-            const float hv = pin(r.og[u]) * r.tc[u];
-            hst[q][u] = UNIFORM ? hv : lane_select(vmask, hv, hst[q][u]);
-            const float outv = UNIFORM ? hv : lane_select(vmask, hv, 0.0f);
-            hb[q * HB + (j0 + u) * 32 + c.cl] = hst[q][u];
-            if (last_layer) hsum[q][u] += outv;
-            else yout[q][(int64_t)t * HB + (j0 + u) * 32 + c.cl] = MASKED ? __fmul_rn(mmid[q][u], outv) : outv;
+#pragma unroll
+        for (int uu = 0; uu < UPP; ++uu) {
+            const int u = up * UPP + uu;
+            if (st == 0) r.ig[u] = sigmoid_exp2(pin(acc[u]));
+            else if (st == 1) r.gg[u] = fmaf(-2.0f * K2, rcp_1p_exp2(pin(acc[8 + u])), K2);                   // K2 * tanh(a_g)
+            else if (st == 2) r.fg[u] = sigmoid_exp2(pin(acc[4 + u]));
+            else if (st == 3) {
+                const float cn = fmaf(pin(r.fg[u]), cst[q][u], __fmul_rn(r.ig[u], r.gg[u]));                    // K2 * c_t
+                r.tc[u] = fmaf(-2.0f, rcp_1p_exp2(cn), 1.0f);                                                   // tanh(c_t)
+                cst[q][u] = UNIFORM ? cn : lane_select(vmask, cn, cst[q][u]);
+            } else if (st == 4) r.og[u] = sigmoid_exp2(pin(acc[12 + u]));
+            else {
+                const float hv = pin(r.og[u]) * r.tc[u];
+                hst[q][u] = UNIFORM ? hv : lane_select(vmask, hv, hst[q][u]);
+                const float outv = UNIFORM ? hv : lane_select(vmask, hv, 0.0f);
+                hb[q * HB + (j0 + u) * 32 + c.cl] = hst[q][u];
+                if (last_layer) hsum[q][u] += outv;
+                else yout[q][(int64_t)t * HB + (j0 + u) * 32 + c.cl] = MASKED ? __fmul_rn(mmid[q][u], outv) : outv;
+            }
         }
     };
     // One pipeline phase: the MFMA chain of tile qc (into accc), with the cell update of tile qa (from acca, step ta)
