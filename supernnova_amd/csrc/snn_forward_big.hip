@@ -345,7 +345,7 @@ pass2:
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
                     if (!TRAIN && r >= SNN_BIG_AG)      // (training: the tape staging changes the allocation, and the form costs there: 28.2 -> 32.8 ms)
-                        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[r]) : "a"(wh[r][kk]), "v"(b));
+                        asm volatile(SNN_AGPR_MFMA : "+a"(acc[r]) : "a"(wh[r][kk]), "v"(b));
                     else
                         acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r][kk], b, acc[r], 0, 0, 0);
                 }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
             const float b = bx[kk];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[0][kk], b, acc[0], 0, 0, 0);
             if (CELL == 1) {
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[1]) : "a"(wx[1][kk]), "v"(b));
+                asm volatile(SNN_AGPR_MFMA : "+a"(acc[1]) : "a"(wx[1][kk]), "v"(b));
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wx[2][kk], b, acc[2], 0, 0, 0);
             }
             bx[kk] = xload(xbn, kk);
@@ -133,8 +133,8 @@ __device__ __forceinline__ void wpt_phase(const FwdParams& p, const WaveCtx& c, 
             const float b = hl[kk * 64 + c.lane];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[0][kk], b, acc[0], 0, 0, 0);
             if (CELL == 1) {
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[1]) : "a"(wh[1][kk]), "v"(b));
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[3]) : "a"(wh[2][kk]), "v"(b));
+                asm volatile(SNN_AGPR_MFMA : "+a"(acc[1]) : "a"(wh[1][kk]), "v"(b));
+                asm volatile(SNN_AGPR_MFMA : "+a"(acc[3]) : "a"(wh[2][kk]), "v"(b));
             }
         }
         if (CELL == 1) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (wait states between a 16-pass MFMA and a vector read of its result)

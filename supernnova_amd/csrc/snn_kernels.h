@@ -8,6 +8,16 @@
 #include "snn_device.h"
 #include "snn_layout.h"
 
+// v_mfma_f32_32x32x2_f32 with its A operand read from an AGPR, as inline asm (the builtin only takes VGPR sources):
+//   asm volatile(SNN_AGPR_MFMA : "+a"(acc) : "a"(w), "v"(b));
+// The compiler does not know this is a matrix instruction, so it inserts none of the wait states one needs.  Before it:
+// when the value lives in a VGPR the compiler copies it with v_accvgpr_write_b32 right in front of the asm, and an
+// MFMA that reads a register a VALU instruction wrote needs 2 wait states (a version whose copies sat directly in front
+// of the MFMAs computed wrong W_hh products, caught by the fixtures) -- the s_nop 1 here provides them whatever the
+// allocation; it issues in the shadow of the previous MFMA.  After it: the caller puts `s_nop 15; s_nop 3` between the
+// last such MFMA and the first VALU read of its accumulator.  microbench/check_agpr_hazard.py scans a listing for both.
+#define SNN_AGPR_MFMA "s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+
 // Dropout masks as the kernels see them (host: snn_masks).
 struct MaskP {
     int mode, which, mid_T;
