@@ -1,5 +1,9 @@
-import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""Debug aid, not collected by pytest (GPU): the H = 128 forward against the oracle on a 32-curve, 2-step case with parts
+of the weights zeroed (W_hh, the biases, all of W_hh but one gate) -- isolates which product a wrong logit comes from.
+   python tests/dbg_h128_forward.py"""
+import os, sys, numpy as np, torch
+_here = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_here)); sys.path.insert(0, _here)
 import oracle
 from supernnova_amd import engine as E
 from util import make_curves
